@@ -1,0 +1,144 @@
+/*
+ * mpc_amd.h -- C ABI of the batched CoM-MPC QP solver for AMD MI355X (gfx950).
+ *
+ * The reference (mfocchi/mpc) has no plugin or FFI layer; the boundary this
+ * library sits behind is the public surface of class MPCPlanner
+ * (include/crawl_planner/MPCPlanner.h:47-143).  Each entry point below names the
+ * MPCPlanner methods whose work it performs for a whole batch of independent
+ * planner calls.  Plain C: pointers, sizes, no C++ or torch types.
+ *
+ * Conventions
+ *   - Per-instance vectors are rows: array[instance][component], contiguous.
+ *     One wavefront works on one instance, so a row is read/written by 64 lanes
+ *     at consecutive addresses.
+ *   - Legs are in iit::dog::LegID order LF=0, RF=1, LH=2, RH=3
+ *     (include/crawl_planner/leg_data_map.h:19).
+ *   - `*_device` entry points take DEVICE pointers, enqueue work on `stream`
+ *     (a hipStream_t passed as void*; NULL = default stream) and return without
+ *     synchronising.  The other entry points take HOST pointers, copy, solve and
+ *     synchronise.
+ *   - Return value: 0 (or a non-negative count where stated) on success, a
+ *     negative MPCB_E_* code on failure; mpcb_last_error() gives the message.
+ *   - Thread compatibility: one handle may be used by one host thread at a time.
+ */
+#ifndef MPC_AMD_H_
+#define MPC_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Formulations.  The numbering is this library's own. */
+enum {
+    MPCB_BOX_1D       = 0, /* MPCPlanner::solveQPconstraint              (MPCPlanner.cpp:240-300) */
+    MPCB_COUPLED_JERK = 1, /* MPCPlanner::solveQPConstraintCoupled, 7-arg (MPCPlanner.cpp:427-490) */
+    MPCB_COUPLED_VEL  = 2, /* MPCPlanner::solveQPConstraintCoupled, 9-arg (MPCPlanner.cpp:493-628) */
+    MPCB_COUPLED_REF  = 3, /* MPCPlanner::solveQPConstraintCoupledRef     (MPCPlanner.cpp:632-783) */
+    MPCB_UNCONSTRAINED = 4 /* MPCPlanner::solveQP                         (MPCPlanner.cpp:223-237) */
+};
+
+/* Per-instance status written to mpcb_outputs.status. */
+enum {
+    MPCB_OK         = 0,
+    MPCB_INFEASIBLE = 1, /* solve_quadprog returned +inf (eiquadprog.hpp:350-356); outputs zero-filled */
+    MPCB_ITER_CAP   = 2  /* iteration cap hit (the reference has no cap and would keep going) */
+};
+
+/* Error codes (negative returns). */
+enum {
+    MPCB_E_ARG    = -1, /* bad argument / unsupported size */
+    MPCB_E_HIP    = -2, /* a HIP runtime call failed */
+    MPCB_E_NUMERIC = -3, /* the Hessian is not positive definite */
+    MPCB_E_NOGPU  = -4  /* no usable device */
+};
+
+/* Constructor arguments.  Replaces MPCPlanner::MPCPlanner (MPCPlanner.cpp:22-70),
+ * setWeights (:94-98), setHipOffsets (:1352-1355) and the `actual_height`,
+ * `replanningWindow`, `number_of_steps` arguments of the solve/computeSteps calls,
+ * which are the same for every instance of a batch. */
+typedef struct {
+    int32_t horizon;            /* horizon_size_                                   */
+    int32_t formulation;        /* MPCB_*                                          */
+    double  Ts;                 /* sample time                                     */
+    double  gravity;
+    double  height;             /* actual_height                                   */
+    double  weight_R;           /* jerk weight                                     */
+    double  weight_Q;           /* velocity weight                                 */
+    double  weight_Qs;          /* ZMP-reference weight (COUPLED_REF only)         */
+    int32_t replanning_window;  /* 1000 = constant velocity weights (MPCPlanner.cpp:535);
+                                   otherwise Gaussian weights, makeGaussian (:1161-1171) */
+    int32_t number_of_steps;    /* computeSteps' number_of_steps (coupled only)    */
+    double  hip_offsets[8];     /* [leg][x,y]; the reference reads them uninitialised
+                                   unless setHipOffsets was called; here explicit  */
+    int32_t iter_cap;           /* cap on outer iterations and on step-direction passes;
+                                   0 = default (50*(n+m))                          */
+    int32_t device;             /* HIP device ordinal                              */
+} mpcb_params;
+
+typedef struct mpcb_handle_s *mpcb_handle;
+
+/* Inputs of a batch of coupled planner calls: the arguments of computeSteps
+ * (MPCPlanner.cpp:1188-1193) and of solveQPConstraintCoupled[Ref].            */
+typedef struct {
+    const double  *x0;        /* [B][3] initial_state_x (pos, vel, acc)                */
+    const double  *y0;        /* [B][3] initial_state_y                                 */
+    const double  *speed;     /* [B][2] userSpeed == targetSpeed (per-step displacement
+                                        in computeSteps, velocity target in the QP)    */
+    const double  *feet_x;    /* [B][4] initial_feet_x                                  */
+    const double  *feet_y;    /* [B][4] initial_feet_y                                  */
+    const int32_t *swing0;    /* [B]    swing_leg_index (LegID)                         */
+    const double  *com0;      /* [B][2] initialCoM; (0,0) = no step correction; may be NULL */
+} mpcb_coupled_inputs;
+
+/* Outputs.  Any pointer may be NULL (that output is skipped). */
+typedef struct {
+    double  *jerk_x, *jerk_y;   /* [B][N] jerk_vector_x / _y                              */
+    double  *com_x, *com_y;     /* [B][N] computeCOMtrajectory(..., POSITION)   (:196-205) */
+    double  *com_xd, *com_yd;   /* [B][N] computeCOMtrajectory(..., VELOCITY)   (:206-209) */
+    double  *zmp_x, *zmp_y;     /* [B][N] computeZMPtrajectory                  (:169-174) */
+    double  *min_margin;        /* [B][N] getConstraintViolation                (:1132-1153) */
+    double  *cost;              /* [B]    value returned by solve_quadprog (1/2 x'Gx + g0'x) */
+    int32_t *status;            /* [B]    MPCB_OK / _INFEASIBLE / _ITER_CAP                */
+    int32_t *iters;             /* [B]    outer iterations (eiquadprog.hpp:240)            */
+    int32_t *n_active;          /* [B]    size of the final working set                    */
+    int32_t *active_idx;        /* [B][active_stride] constraint rows of the final working
+                                          set in the order the solver holds them, -1 padded */
+    double  *multipliers;       /* [B][active_stride] their Lagrange multipliers          */
+    int32_t  active_stride;
+} mpcb_outputs;
+
+/* Builds every instance-independent matrix (prediction matrices, condensed
+ * Hessian, its factor and the response matrices) and uploads them. */
+int  mpcb_create(const mpcb_params *params, mpcb_handle *out);
+void mpcb_destroy(mpcb_handle h);
+const char *mpcb_last_error(void);
+
+/* Number of inequality rows m of one instance (700 for N=200, 20 steps; 2N for BOX_1D). */
+int  mpcb_num_constraints(mpcb_handle h);
+
+/* Coupled XY plan: computeSteps -> [computeCentroid] -> solveQPConstraintCoupled[Ref]
+ * -> getConstraintViolation -> computeZMP/COMtrajectory for B instances. */
+int  mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in,
+                               const mpcb_outputs *out, void *stream);
+int  mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in,
+                        const mpcb_outputs *out);
+
+/* 1-D box-constrained plan: solveQPconstraint for B instances (one axis each).
+ * x0 [B][3], zmin/zmax [B][N] (BoxLimits, MPCPlanner.h:29-34).  Outputs: the *_x
+ * members; active_idx < N is the lower bound of that knot, >= N the upper bound. */
+int  mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const double *zmin,
+                           const double *zmax, const mpcb_outputs *out, void *stream);
+int  mpcb_solve_box(mpcb_handle h, int32_t B, const double *x0, const double *zmin,
+                    const double *zmax, const mpcb_outputs *out);
+
+/* Copy an instance-independent matrix to the host (tests, diagnostics).
+ * which: 0 = S (ZMP response, N x N), 1 = W^T (jerk response), 2 = CoM position
+ * response, 3 = CoM velocity response, 4 = Kz (N x 4), 5 = Kx (N x 4).      */
+int  mpcb_get_matrix(mpcb_handle h, int32_t which, double *dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_AMD_H_ */

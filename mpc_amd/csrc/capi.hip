@@ -1,0 +1,290 @@
+// C ABI (include/mpc_amd.h): handle life-cycle, table upload, host-pointer wrappers.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "setup.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(MPCB_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+template <class T> int upload(const std::vector<T> &h, T **d) {
+    *d = nullptr;
+    if (h.empty()) return 0;
+    HIP_TRY(hipMalloc((void **)d, h.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+} // namespace
+
+struct mpcb_handle_s {
+    mpcb_params params;
+    mpcb::HostSetup hs;
+    mpcb::DevSetup ds;
+    std::vector<void *> dev_allocs;
+};
+
+namespace {
+
+template <class T> int upload_to(mpcb_handle h, const std::vector<T> &v, const T **dst) {
+    T *p = nullptr;
+    int rc = upload(v, &p);
+    if (rc) return rc;
+    if (p) h->dev_allocs.push_back(p);
+    *dst = p;
+    return 0;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// Scratch copies for the host-pointer entry points.
+struct Staging {
+    std::vector<void *> bufs;
+    ~Staging() {
+        for (void *p : bufs) (void)hipFree(p);
+    }
+    template <class T> int in(const T *host, size_t n, const T **dev) {
+        *dev = nullptr;
+        if (!host || !n) return 0;
+        T *p = nullptr;
+        HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
+        bufs.push_back(p);
+        HIP_TRY(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+        *dev = p;
+        return 0;
+    }
+    template <class T> int out(T *host, size_t n, T **dev) {
+        *dev = nullptr;
+        if (!host || !n) return 0;
+        T *p = nullptr;
+        HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
+        bufs.push_back(p);
+        *dev = p;
+        return 0;
+    }
+};
+
+int stage_outputs(Staging &st, const mpcb_outputs &h, mpcb_outputs &d, size_t B, size_t N) {
+    int rc = 0;
+    d = h;
+#define OUT_(field, n) \
+    if ((rc = st.out(h.field, (n), &d.field))) return rc;
+    OUT_(jerk_x, B * N) OUT_(jerk_y, B * N) OUT_(com_x, B * N) OUT_(com_y, B * N)
+    OUT_(com_xd, B * N) OUT_(com_yd, B * N) OUT_(zmp_x, B * N) OUT_(zmp_y, B * N)
+    OUT_(min_margin, B * N) OUT_(cost, B) OUT_(status, B) OUT_(iters, B) OUT_(n_active, B)
+    OUT_(active_idx, B * (size_t)h.active_stride) OUT_(multipliers, B * (size_t)h.active_stride)
+#undef OUT_
+    return 0;
+}
+
+int fetch_outputs(const mpcb_outputs &h, const mpcb_outputs &d, size_t B, size_t N) {
+#define BACK_(field, n)                                                                       \
+    if (h.field)                                                                              \
+        HIP_TRY(hipMemcpy(h.field, d.field, (n) * sizeof(*h.field), hipMemcpyDeviceToHost));
+    BACK_(jerk_x, B * N) BACK_(jerk_y, B * N) BACK_(com_x, B * N) BACK_(com_y, B * N)
+    BACK_(com_xd, B * N) BACK_(com_yd, B * N) BACK_(zmp_x, B * N) BACK_(zmp_y, B * N)
+    BACK_(min_margin, B * N) BACK_(cost, B) BACK_(status, B) BACK_(iters, B) BACK_(n_active, B)
+    BACK_(active_idx, B * (size_t)h.active_stride) BACK_(multipliers, B * (size_t)h.active_stride)
+#undef BACK_
+    return 0;
+}
+
+int count_not_ok(const int32_t *status, int B) {
+    int n = 0;
+    if (status)
+        for (int i = 0; i < B; i++) n += status[i] != MPCB_OK;
+    return n;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *mpcb_last_error(void) { return g_err.c_str(); }
+
+int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
+    if (!params || !out) return fail(MPCB_E_ARG, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MPCB_E_NOGPU, "no HIP device available");
+    if (params->device < 0 || params->device >= ndev) return fail(MPCB_E_ARG, "device ordinal out of range");
+    mpcb_handle h = new mpcb_handle_s();
+    h->params = *params;
+    const char *err = "";
+    int rc = mpcb::build_setup(*params, h->hs, &err);
+    if (rc) {
+        delete h;
+        return fail(rc, err);
+    }
+    DeviceGuard guard(params->device);
+    if (!guard.ok) {
+        delete h;
+        return fail(MPCB_E_HIP, "hipSetDevice failed");
+    }
+    const mpcb::HostSetup &hs = h->hs;
+    mpcb::DevSetup &ds = h->ds;
+    std::memset(&ds, 0, sizeof(ds));
+    ds.N = hs.N;
+    ds.m = hs.m;
+    ds.axes = hs.axes;
+    ds.form = params->formulation;
+    ds.steps = hs.steps;
+    ds.phase_knots = hs.phase_knots;
+    ds.nphase = hs.nphase;
+    const int n = hs.N * hs.axes;
+    ds.iter_cap = params->iter_cap > 0 ? params->iter_cap : 50 * (n + hs.m);
+    std::memcpy(ds.F, hs.F, sizeof(ds.F));
+    ds.psi_thr = (double)hs.m * 2.220446049250313e-16 * hs.c1 * hs.c2 * 100.0;
+    ds.traceG1 = hs.traceG1;
+    std::memcpy(ds.hip, params->hip_offsets, sizeof(ds.hip));
+    if ((rc = upload_to(h, hs.S, &ds.S)) || (rc = upload_to(h, hs.Wt, &ds.Wt)) ||
+        (rc = upload_to(h, hs.Sc, &ds.Sc)) || (rc = upload_to(h, hs.Sv, &ds.Sv)) ||
+        (rc = upload_to(h, hs.Kx, &ds.Kx)) || (rc = upload_to(h, hs.Kz, &ds.Kz)) ||
+        (rc = upload_to(h, hs.Kc, &ds.Kc)) || (rc = upload_to(h, hs.Kv, &ds.Kv)) ||
+        (rc = upload_to(h, hs.knot_phase, &ds.knot_phase)) ||
+        (rc = upload_to(h, hs.knot_row0, &ds.knot_row0))) {
+        mpcb_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+void mpcb_destroy(mpcb_handle h) {
+    if (!h) return;
+    {
+        DeviceGuard guard(h->params.device);
+        for (void *p : h->dev_allocs) (void)hipFree(p);
+    }
+    delete h;
+}
+
+int mpcb_num_constraints(mpcb_handle h) { return h ? h->hs.m : MPCB_E_ARG; }
+
+int mpcb_get_matrix(mpcb_handle h, int32_t which, double *dst) {
+    if (!h || !dst) return fail(MPCB_E_ARG, "null argument");
+    const mpcb::HostSetup &hs = h->hs;
+    const std::vector<double> *src = nullptr;
+    switch (which) {
+    case 0: src = &hs.S; break;
+    case 1: src = &hs.Wt; break;
+    case 2: src = &hs.Sc; break;
+    case 3: src = &hs.Sv; break;
+    case 4: src = &hs.Kz; break;
+    case 5: src = &hs.Kx; break;
+    default: return fail(MPCB_E_ARG, "unknown matrix id");
+    }
+    std::memcpy(dst, src->data(), src->size() * sizeof(double));
+    return 0;
+}
+
+int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in,
+                              const mpcb_outputs *out, void *stream) {
+    if (!h || !in || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
+    const int form = h->params.formulation;
+    if (form != MPCB_COUPLED_JERK && form != MPCB_COUPLED_VEL)
+        return fail(MPCB_E_ARG, "handle was not created for a coupled formulation supported here");
+    if (!in->x0 || !in->y0 || !in->speed || !in->feet_x || !in->feet_y || !in->swing0)
+        return fail(MPCB_E_ARG, "missing coupled input array");
+    if ((out->active_idx || out->multipliers) && out->active_stride <= 0)
+        return fail(MPCB_E_ARG, "active_stride must be positive");
+    DeviceGuard guard(h->params.device);
+    mpcb::DevIn di;
+    std::memset(&di, 0, sizeof(di));
+    di.x0 = in->x0;
+    di.y0 = in->y0;
+    di.speed = in->speed;
+    di.feet_x = in->feet_x;
+    di.feet_y = in->feet_y;
+    di.swing0 = in->swing0;
+    di.com0 = in->com0;
+    HIP_TRY(mpcb::launch_zspace(h->ds, di, *out, B, (hipStream_t)stream));
+    return 0;
+}
+
+int mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const double *zmin,
+                          const double *zmax, const mpcb_outputs *out, void *stream) {
+    if (!h || !x0 || !zmin || !zmax || !out || B < 0)
+        return fail(MPCB_E_ARG, "null argument or negative batch");
+    if (h->params.formulation != MPCB_BOX_1D) return fail(MPCB_E_ARG, "handle was not created for BOX_1D");
+    if ((out->active_idx || out->multipliers) && out->active_stride <= 0)
+        return fail(MPCB_E_ARG, "active_stride must be positive");
+    DeviceGuard guard(h->params.device);
+    mpcb::DevIn di;
+    std::memset(&di, 0, sizeof(di));
+    di.x0 = x0;
+    di.zmin = zmin;
+    di.zmax = zmax;
+    HIP_TRY(mpcb::launch_zspace(h->ds, di, *out, B, (hipStream_t)stream));
+    return 0;
+}
+
+int mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, const mpcb_outputs *out) {
+    if (!h || !in || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
+    DeviceGuard guard(h->params.device);
+    Staging st;
+    mpcb_coupled_inputs di;
+    std::memset(&di, 0, sizeof(di));
+    int rc;
+    const size_t b = (size_t)B, N = (size_t)h->hs.N;
+    if ((rc = st.in(in->x0, b * 3, &di.x0)) || (rc = st.in(in->y0, b * 3, &di.y0)) ||
+        (rc = st.in(in->speed, b * 2, &di.speed)) || (rc = st.in(in->feet_x, b * 4, &di.feet_x)) ||
+        (rc = st.in(in->feet_y, b * 4, &di.feet_y)) || (rc = st.in(in->swing0, b, &di.swing0)) ||
+        (rc = st.in(in->com0, b * 2, &di.com0)))
+        return rc;
+    mpcb_outputs dout;
+    if ((rc = stage_outputs(st, *out, dout, b, N))) return rc;
+    if ((rc = mpcb_solve_coupled_device(h, B, &di, &dout, nullptr))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = fetch_outputs(*out, dout, b, N))) return rc;
+    return count_not_ok(out->status, B);
+}
+
+int mpcb_solve_box(mpcb_handle h, int32_t B, const double *x0, const double *zmin, const double *zmax,
+                   const mpcb_outputs *out) {
+    if (!h || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
+    DeviceGuard guard(h->params.device);
+    Staging st;
+    const double *dx0, *dmin, *dmax;
+    int rc;
+    const size_t b = (size_t)B, N = (size_t)h->hs.N;
+    if ((rc = st.in(x0, b * 3, &dx0)) || (rc = st.in(zmin, b * N, &dmin)) || (rc = st.in(zmax, b * N, &dmax)))
+        return rc;
+    mpcb_outputs dout;
+    if ((rc = stage_outputs(st, *out, dout, b, N))) return rc;
+    if ((rc = mpcb_solve_box_device(h, B, dx0, dmin, dmax, &dout, nullptr))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = fetch_outputs(*out, dout, b, N))) return rc;
+    return count_not_ok(out->status, B);
+}
+
+} // extern "C"

@@ -1,0 +1,792 @@
+// Structure-exploiting dual active-set QP kernel: ONE WAVEFRONT PER QP.
+//
+// The reference solves  min 1/2 x'Gx + g0'x  s.t. CI'x + ci0 >= 0  with the dense
+// Goldfarb-Idnani method (eiquadprog.hpp:130-447) after assembling G (n x n) and
+// CI (n x m) densely (MPCPlanner.cpp:427-783).  Here the same method -- same pivot
+// rules, tolerances and step formulas -- runs on the multipliers u of the working
+// set A only, because for this planner
+//   * G = blkdiag(G1, G1) is the same for every instance, and
+//   * row j of CI' is a half-plane on the ZMP at ONE knot k_j:
+//         s_j = p_j zx[k_j] + q_j zy[k_j] + r_j,   zx = Zx x0 + Zu jerk_x.
+// With W = G1^-1 Zu' and S = Zu W (instance-independent, read through L2):
+//         zmp = zmp_unc + sum_a (u_a p_a) S[k_a, :]
+//         n_i' G^-1 n_j = (p_i p_j + q_i q_j) S[k_i, k_j]
+// so a solve needs only the q x q triangular factor R of the working set
+// (R'R = N_A' G^-1 N_A, which is also the R of the reference's QR update) and its
+// inverse.  Both live in LDS; nothing n x n or m x n is ever formed.
+//
+// Layout: 256-thread blocks = 4 independent waves, no workgroup barrier anywhere.
+// Lane l owns knots l, l+64, ... and the (at most 4) constraint rows of each of
+// them, in registers.  Cross-lane data goes through the wave's private LDS slice
+// or through wave shuffles.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace mpcb {
+namespace {
+
+constexpr int QL = 32;                   // capacity of the LDS-resident factor
+constexpr int TRI = QL * (QL + 1) / 2;   // packed upper triangle, column-major
+constexpr double EPS = 2.220446049250313e-16;
+constexpr double DINF = __builtin_huge_val();
+
+struct WaveState {
+    double R[TRI];
+    double Rinv[TRI];
+    double wsU[QL + 1], wsP[QL + 1], wsQ[QL + 1];       // working set: multiplier, p, q
+    double oldU[QL + 1], oldP[QL + 1], oldQ[QL + 1];    // copy taken at step 1 (eiquadprog.hpp:275-277)
+    double g[QL + 1], d[QL + 1], cx[QL + 1], cy[QL + 1];
+    int wsRow[QL + 1], wsKS[QL + 1];                    // constraint row; (knot << 2) | slot
+    int oldRow[QL + 1], oldKS[QL + 1];
+    int pad[4];
+};
+static_assert(sizeof(WaveState) % 8 == 0, "tab must stay 8-byte aligned");
+
+// LDS traffic between lanes of one wave: the hardware executes a wave's LDS
+// instructions in order, so only the compiler has to be kept from reordering.
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int ufirst(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ double ufirst(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return ufirst(v);
+}
+
+// Minimum of (val, key); the smaller key wins ties.  Result is wave-uniform.
+__device__ __forceinline__ void wave_argmin(double &val, int &key, int &aux) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(val, o, 64);
+        const int ok = __shfl_xor(key, o, 64);
+        const int oa = __shfl_xor(aux, o, 64);
+        if (ov < val || (ov == val && ok < key)) {
+            val = ov;
+            key = ok;
+            aux = oa;
+        }
+    }
+    val = ufirst(val);
+    key = ufirst(key);
+    aux = ufirst(aux);
+}
+
+// eiquadprog.hpp:90-108
+__device__ __forceinline__ double distance(double a, double b) {
+    const double a1 = fabs(a), b1 = fabs(b);
+    if (a1 > b1) {
+        const double t = b1 / a1;
+        return a1 * sqrt(1.0 + t * t);
+    } else if (b1 > a1) {
+        const double t = a1 / b1;
+        return b1 * sqrt(1.0 + t * t);
+    }
+    return a1 * sqrt(2.0);
+}
+
+__device__ __forceinline__ int tri(int col) { return col * (col + 1) / 2; }
+
+// Remove working-set position qq (delete_constraint, eiquadprog.hpp:516-592).
+// R loses column qq and is re-triangularised by Givens rotations of rows (j, j+1);
+// the same rotations applied to the columns of R^-1, minus row qq and the last
+// column, give the new inverse -- what the reference does to the columns of J.
+__device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq, int qq) {
+    // working-set arrays: positions qq+1 .. iq-1 move down by one
+    double tu = 0, tp = 0, tq = 0;
+    int trow = 0, tks = 0;
+    const bool mv = lane > qq && lane < iq;
+    if (mv) {
+        tu = W.wsU[lane];
+        tp = W.wsP[lane];
+        tq = W.wsQ[lane];
+        trow = W.wsRow[lane];
+        tks = W.wsKS[lane];
+    }
+    wsync();
+    if (mv) {
+        W.wsU[lane - 1] = tu;
+        W.wsP[lane - 1] = tp;
+        W.wsQ[lane - 1] = tq;
+        W.wsRow[lane - 1] = trow;
+        W.wsKS[lane - 1] = tks;
+    }
+    const int last = iq - 2; // new column / rotation index runs qq .. iq-2
+    if (qq <= last) {
+        // R: lane k builds new column k from old column k+1
+        const bool rk = lane >= qq && lane <= last;
+        const int offn = tri(lane), offo = tri(lane + 1);
+        for (int i = 0; i < qq; i++) {
+            double v = 0;
+            if (rk) v = W.R[offo + i];
+            wsync();
+            if (rk) W.R[offn + i] = v;
+        }
+        double top = rk ? W.R[offo + qq] : 0.0;
+        // R^-1: lane i carries row i
+        const bool ri = lane < iq;
+        double tcur = (ri && lane <= qq) ? W.Rinv[tri(qq) + lane] : 0.0;
+        const int inew = lane < qq ? lane : lane - 1;
+        wsync();
+        for (int j = qq; j <= last; j++) {
+            const bool act = rk && lane >= j;
+            const double bot = act ? W.R[offo + j + 1] : 0.0;
+            const double t2 = (ri && lane <= j + 1) ? W.Rinv[tri(j + 1) + lane] : 0.0;
+            const double tj = __shfl(top, j, 64), bj = __shfl(bot, j, 64);
+            const double h = distance(tj, bj);
+            wsync();
+            if (h == 0.0) {
+                if (act) {
+                    W.R[offn + j] = top;
+                    top = bot;
+                }
+                if (ri && lane != qq && inew <= j) W.Rinv[tri(j) + inew] = tcur;
+                tcur = t2;
+                continue;
+            }
+            double cc = tj / h, ss = bj / h, hd = h;
+            if (cc < 0.0) {
+                cc = -cc;
+                ss = -ss;
+                hd = -h;
+            }
+            if (act) {
+                if (lane == j) {
+                    W.R[offn + j] = hd;
+                } else {
+                    W.R[offn + j] = cc * top + ss * bot;
+                    top = ss * top - cc * bot;
+                }
+            }
+            if (ri && lane != qq && inew <= j) W.Rinv[tri(j) + inew] = cc * tcur + ss * t2;
+            tcur = ss * tcur - cc * t2;
+        }
+    }
+    iq--;
+    wsync();
+}
+
+template <int NPL, bool POLY>
+__global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B) {
+    constexpr int ES = POLY ? 4 : 2;
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = ufirst((int)(threadIdx.x >> 6));
+    const int inst = ufirst((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (inst >= B) return;
+    const int N = sd.N;
+    const int tab_doubles = POLY ? sd.nphase * 12 : 0;
+    const int per_wave = (int)(sizeof(WaveState) / 8) + tab_doubles;
+    WaveState &W = *reinterpret_cast<WaveState *>(smem + (size_t)wv * per_wave);
+    double *tab = smem + (size_t)wv * per_wave + sizeof(WaveState) / 8; // [phase][edge][p,q,r]
+
+    // ---- owned knots ------------------------------------------------------
+    int kn[NPL], kc[NPL];
+    unsigned validm = 0; // bit (c*4+e): the slot exists
+#pragma unroll
+    for (int c = 0; c < NPL; c++) {
+        kn[c] = lane + 64 * c;
+        kc[c] = kn[c] < N ? kn[c] : N - 1;
+    }
+
+    // ---- instance inputs (wave-uniform addresses) -------------------------
+    double wx[4], wy[4];
+    {
+        const double *px = in.x0 + (size_t)inst * 3;
+        wx[0] = px[0];
+        wx[1] = px[1];
+        wx[2] = px[2];
+        wx[3] = 0.0;
+        wy[0] = wy[1] = wy[2] = wy[3] = 0.0;
+        if constexpr (POLY) {
+            const double *py = in.y0 + (size_t)inst * 3;
+            wy[0] = py[0];
+            wy[1] = py[1];
+            wy[2] = py[2];
+            wx[3] = in.speed[(size_t)inst * 2];
+            wy[3] = in.speed[(size_t)inst * 2 + 1];
+        }
+    }
+
+    // ---- constraint rows ---------------------------------------------------
+    int ph[NPL], row0[NPL];
+    double lo[NPL], hi[NPL];
+#pragma unroll
+    for (int c = 0; c < NPL; c++) {
+        ph[c] = 0;
+        row0[c] = kn[c];
+        lo[c] = hi[c] = 0.0;
+    }
+    if constexpr (POLY) {
+        // computeSteps (MPCPlanner.cpp:1188-1329): every lane replays the footstep
+        // schedule (it is the same for the whole wave) and keeps the feet of the
+        // phase it is responsible for; then it builds that phase's polygon
+        // (buildPolygonMatrix, :1040-1082).
+        const double *pfx = in.feet_x + (size_t)inst * 4, *pfy = in.feet_y + (size_t)inst * 4;
+        const double spx = wx[3], spy = wy[3];
+        double c0x = 0.0, c0y = 0.0;
+        if (in.com0) {
+            c0x = in.com0[(size_t)inst * 2];
+            c0y = in.com0[(size_t)inst * 2 + 1];
+        }
+        const bool correct = !(c0x == 0.0 && c0y == 0.0); // initialCoM.isZero(0), :1231
+        const int swing0 = in.swing0[inst];
+        // schedule LF, RH, RF, LH (:1197); setCurrentSwing (FootScheduler.h:33-43)
+        int cur0 = 0;
+        if (swing0 == 3) cur0 = 1;
+        else if (swing0 == 1) cur0 = 2;
+        else if (swing0 == 2) cur0 = 3;
+        for (int pbase = 0; pbase < sd.nphase; pbase += 64) {
+            const int myph = pbase + lane;
+            double fx[4], fy[4], sx[4], sy[4], corrx[4], corry[4];
+            bool flag[4];
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                fx[l] = pfx[l];
+                fy[l] = pfy[l];
+                sx[l] = fx[l];
+                sy[l] = fy[l];
+                flag[l] = correct;
+                corrx[l] = ((c0x + sd.hip[2 * l]) + spx) - fx[l];     // :1234-1237
+                corry[l] = ((c0y + sd.hip[2 * l + 1]) + spy) - fy[l];
+            }
+            int excl = -1, cur = cur0;
+            for (int i = 0; i < sd.steps; i++) {
+                if (myph == 2 * i) {
+#pragma unroll
+                    for (int l = 0; l < 4; l++) {
+                        sx[l] = fx[l];
+                        sy[l] = fy[l];
+                    }
+                    excl = -1;
+                }
+                const int sw = (cur == 0) ? 0 : (cur == 1) ? 3 : (cur == 2) ? 1 : 2;
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    if (l == sw) {
+                        const double dx = flag[l] ? corrx[l] : spx; // :1266-1280
+                        const double dy = flag[l] ? corry[l] : spy;
+                        flag[l] = false;
+                        fx[l] += dx;
+                        fy[l] += dy;
+                    }
+                }
+                if (myph == 2 * i + 1) {
+#pragma unroll
+                    for (int l = 0; l < 4; l++) {
+                        sx[l] = fx[l];
+                        sy[l] = fy[l];
+                    }
+                    excl = sw;
+                }
+                cur = (cur + 1) & 3;
+            }
+            if (myph == 2 * sd.steps) {
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    sx[l] = fx[l];
+                    sy[l] = fy[l];
+                }
+                excl = -1;
+            }
+            if (myph < sd.nphase) {
+                const int E = excl < 0 ? 4 : 3;
+                double px[4], py[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { // stance feet in LegID order (:1052-1059)
+                    const int leg = e + ((excl >= 0 && e >= excl) ? 1 : 0);
+                    px[e] = leg == 0 ? sx[0] : leg == 1 ? sx[1] : leg == 2 ? sx[2] : sx[3];
+                    py[e] = leg == 0 ? sy[0] : leg == 1 ? sy[1] : leg == 2 ? sy[2] : sy[3];
+                }
+                // CounterClockwiseSort (planning.h:182-197), pivot p[0]
+                auto right_of = [&](int a, int b) { // Point2isRightOfLine(p0, pa, pb), :143-149
+                    return (px[b] - px[0]) * (py[a] - py[0]) - (px[a] - px[0]) * (py[b] - py[0]);
+                };
+                auto swp = [&](int a, int b) {
+                    double t = px[a];
+                    px[a] = px[b];
+                    px[b] = t;
+                    t = py[a];
+                    py[a] = py[b];
+                    py[b] = t;
+                };
+                if (right_of(1, 2) > 0.0) swp(1, 2);
+                if (E == 4) {
+                    if (right_of(1, 3) > 0.0) swp(1, 3);
+                    if (right_of(2, 3) > 0.0) swp(2, 3);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (e < E) {
+                        // LineCoeff(pt_e, pt_{(e+1)%E}, normalize) (planning.h:236-260)
+                        const int nx = (e + 1 == E) ? 0 : e + 1;
+                        const double bx = nx == 0 ? px[0] : nx == 1 ? px[1] : nx == 2 ? px[2] : px[3];
+                        const double by = nx == 0 ? py[0] : nx == 1 ? py[1] : nx == 2 ? py[2] : py[3];
+                        double p = py[e] - by, q = bx - px[e];
+                        double r = -p * px[e] - q * py[e];
+                        const double norm = hypot(p, q);
+                        p /= norm;
+                        q /= norm;
+                        r /= norm;
+                        double *t = tab + (myph * 4 + e) * 3;
+                        t[0] = p;
+                        t[1] = q;
+                        t[2] = r;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NPL; c++) {
+            ph[c] = sd.knot_phase[kc[c]];
+            row0[c] = sd.knot_row0[kc[c]];
+            if (kn[c] < N) {
+                const int E = ((ph[c] & 1) && ph[c] < 2 * sd.steps) ? 3 : 4;
+                validm |= ((1u << E) - 1u) << (4 * c);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NPL; c++) {
+            if (kn[c] < N) {
+                lo[c] = in.zmin[(size_t)inst * N + kn[c]];
+                hi[c] = in.zmax[(size_t)inst * N + kn[c]];
+                validm |= 3u << (4 * c);
+            }
+        }
+    }
+    wsync();
+
+    auto slotP = [&](int c, int e) -> double {
+        if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3];
+        else return e == 0 ? 1.0 : -1.0;
+    };
+    auto slotQ = [&](int c, int e) -> double {
+        if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3 + 1];
+        else return 0.0;
+    };
+    auto slotR = [&](int c, int e) -> double {
+        if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3 + 2];
+        else return e == 0 ? -lo[c] : hi[c];
+    };
+    auto slotRow = [&](int c, int e) -> int {
+        if constexpr (POLY) return row0[c] + e;
+        else return kn[c] + e * N;
+    };
+
+    // ---- unconstrained solution (x = -G^-1 g0, eiquadprog.hpp:188-191) ----
+    double zxu[NPL], zyu[NPL];
+#pragma unroll
+    for (int c = 0; c < NPL; c++) {
+        const double *kz = sd.Kz + (size_t)kc[c] * 4;
+        zxu[c] = kz[0] * wx[0] + kz[1] * wx[1] + kz[2] * wx[2] + kz[3] * wx[3];
+        zyu[c] = kz[0] * wy[0] + kz[1] * wy[1] + kz[2] * wy[2] + kz[3] * wy[3];
+    }
+    double f = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) f += sd.F[a * 4 + b] * (wx[a] * wx[b] + wy[a] * wy[b]);
+
+    // ---- dual active-set loop ----------------------------------------------
+    int iq = 0, iters = 0, passes = 0, status = MPCB_OK;
+    unsigned actm = 0, exclm = 0;
+    double R_norm = 1.0;
+    double s[NPL][ES], zx[NPL], zy[NPL];
+    bool pending = false;       // a candidate's partial steps are part of x (cap exit)
+    int ipRow = 0, ipKS = 0;
+    double pip = 0.0, qip = 0.0, ucand = 0.0, s_ip = 0.0;
+
+    for (;;) { // step 1 (l1)
+        iters++;
+        if (iters > sd.iter_cap) {
+            status = MPCB_ITER_CAP;
+            break;
+        }
+        // zmp at x = x_unc + G^-1 N_A u
+        if (lane < iq) {
+            W.cx[lane] = W.wsU[lane] * W.wsP[lane];
+            W.cy[lane] = W.wsU[lane] * W.wsQ[lane];
+        }
+        wsync();
+#pragma unroll
+        for (int c = 0; c < NPL; c++) {
+            zx[c] = zxu[c];
+            zy[c] = zyu[c];
+        }
+        for (int a = 0; a < iq; a++) {
+            const int ka = ufirst(W.wsKS[a]) >> 2;
+            const double ca = W.cx[a], cb = W.cy[a];
+            const double *srow = sd.S + (size_t)ka * N;
+#pragma unroll
+            for (int c = 0; c < NPL; c++) {
+                const double sv = srow[kc[c]];
+                zx[c] += ca * sv;
+                if constexpr (POLY) zy[c] += cb * sv;
+            }
+        }
+        double psi = 0.0;
+#pragma unroll
+        for (int c = 0; c < NPL; c++)
+#pragma unroll
+            for (int e = 0; e < ES; e++) {
+                double v = DINF;
+                if (validm & (1u << (4 * c + e))) v = slotP(c, e) * zx[c] + slotQ(c, e) * zy[c] + slotR(c, e);
+                s[c][e] = v;
+                psi += fmin(0.0, v);
+            }
+        psi = wave_sum(psi);
+        exclm = 0xffffffffu; // iaexcl[i] = true (:257)
+        if (fabs(psi) <= sd.psi_thr) break; // :267-272
+        if (lane < iq) { // :275-277
+            W.oldU[lane] = W.wsU[lane];
+            W.oldP[lane] = W.wsP[lane];
+            W.oldQ[lane] = W.wsQ[lane];
+            W.oldRow[lane] = W.wsRow[lane];
+            W.oldKS[lane] = W.wsKS[lane];
+        }
+        double ssv = 0.0;
+        bool done = false, restart;
+        do { // step 2 (l2), :279-299
+            restart = false;
+            double bv = DINF;
+            int brow = 0x7fffffff, bks = 0;
+#pragma unroll
+            for (int c = 0; c < NPL; c++)
+#pragma unroll
+                for (int e = 0; e < ES; e++) {
+                    const unsigned bit = 1u << (4 * c + e);
+                    const int row = slotRow(c, e);
+                    if ((validm & bit) && !(actm & bit) && (exclm & bit) && s[c][e] < ssv &&
+                        (s[c][e] < bv || (s[c][e] == bv && row < brow))) {
+                        bv = s[c][e];
+                        brow = row;
+                        bks = (kn[c] << 2) | e;
+                    }
+                }
+            wave_argmin(bv, brow, bks);
+            if (bv < ssv) {
+                ssv = bv;
+                ipRow = brow;
+                ipKS = bks;
+                s_ip = bv;
+            }
+            if (ssv >= 0.0) {
+                done = true;
+                break;
+            }
+            const int kip = ipKS >> 2, eip = ipKS & 3;
+            if constexpr (POLY) {
+                const int php = sd.knot_phase[kip];
+                pip = tab[(php * 4 + eip) * 3];
+                qip = tab[(php * 4 + eip) * 3 + 1];
+            } else {
+                pip = eip == 0 ? 1.0 : -1.0;
+                qip = 0.0;
+            }
+            ucand = 0.0; // u(iq) = 0 (:297)
+            pending = true;
+            const double mii = (pip * pip + qip * qip) * sd.S[(size_t)kip * N + kip];
+
+            for (;;) { // step 2a (l2a), :306-446
+                passes++;
+                if (passes > sd.iter_cap) {
+                    status = MPCB_ITER_CAP;
+                    done = true;
+                    break;
+                }
+                // g = N_A' G^-1 n_ip ; d = R^-T g (= J1' n_ip) ; r = R^-1 d
+                double ga = 0.0, da = 0.0, ra = 0.0, ua = 0.0;
+                if (lane < iq) {
+                    const int ka = W.wsKS[lane] >> 2;
+                    ga = (W.wsP[lane] * pip + W.wsQ[lane] * qip) * sd.S[(size_t)ka * N + kip];
+                    ua = W.wsU[lane];
+                }
+                W.g[lane < QL ? lane : QL] = ga;
+                wsync();
+                {
+                    const int off = tri(lane);
+                    for (int j = 0; j < iq; j++) {
+                        const double gj = W.g[j];
+                        if (lane < iq && j <= lane) da += W.Rinv[off + j] * gj;
+                    }
+                }
+                W.d[lane < QL ? lane : QL] = da;
+                wsync();
+                for (int k = 0; k < iq; k++) {
+                    const double dk = W.d[k];
+                    if (lane < iq && k >= lane) ra += W.Rinv[tri(k) + lane] * dk;
+                }
+                const double zn = mii - wave_sum(da * da); // z . n_ip
+                // step 2b: t1 = min u_k / r_k over r_k > 0, first minimum wins (:322-334)
+                double t1 = (lane < iq && ra > 0.0) ? ua / ra : DINF;
+                int apos = lane, dummy = 0;
+                wave_argmin(t1, apos, dummy);
+                // z != 0 test (:336): ||z||^2 >= zn / lambda_max(G1) >= zn / trace(G1)
+                bool znz;
+                if (zn > 1e-8 * mii && zn > 64.0 * EPS * sd.traceG1) {
+                    znz = true;
+                } else {
+                    // explicit z = G^-1 (n_ip - N_A r)
+                    if (lane < iq) {
+                        W.cx[lane] = ra * W.wsP[lane];
+                        W.cy[lane] = ra * W.wsQ[lane];
+                    }
+                    wsync();
+                    double acc = 0.0;
+                    double zvx[NPL], zvy[NPL];
+                    const double *wip = sd.Wt + (size_t)kip * N;
+#pragma unroll
+                    for (int c = 0; c < NPL; c++) {
+                        const double w = wip[kc[c]];
+                        zvx[c] = pip * w;
+                        zvy[c] = qip * w;
+                    }
+                    for (int a = 0; a < iq; a++) {
+                        const int ka = ufirst(W.wsKS[a]) >> 2;
+                        const double ca = W.cx[a], cb = W.cy[a];
+                        const double *wrow = sd.Wt + (size_t)ka * N;
+#pragma unroll
+                        for (int c = 0; c < NPL; c++) {
+                            const double w = wrow[kc[c]];
+                            zvx[c] -= ca * w;
+                            zvy[c] -= cb * w;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NPL; c++)
+                        if (kn[c] < N) acc += zvx[c] * zvx[c] + zvy[c] * zvy[c];
+                    znz = fabs(wave_sum(acc)) > EPS;
+                    wsync();
+                }
+                if (znz && !(zn > 1e-11 * mii)) {
+                    // n_ip is numerically dependent on the working set although z is
+                    // not negligible: the reduced system has lost its accuracy.
+                    status = STATUS_UNRESOLVED;
+                    done = true;
+                    break;
+                }
+                const double t2 = znz ? -s_ip / zn : DINF;
+                const double t = fmin(t1, t2);
+                if (t >= DINF) { // :350-356
+                    status = MPCB_INFEASIBLE;
+                    f = DINF;
+                    done = true;
+                    break;
+                }
+                if (t2 >= DINF) { // dual step only, drop (:358-373)
+                    if (lane < iq) W.wsU[lane] = ua - t * ra;
+                    ucand += t;
+                    const int ksd = ufirst(W.wsKS[apos]);
+                    if (lane == ((ksd >> 2) & 63)) actm &= ~(1u << (4 * ((ksd >> 2) >> 6) + (ksd & 3)));
+                    wsync();
+                    drop_constraint(W, lane, iq, apos);
+                    continue;
+                }
+                // step in primal and dual space (:377-382)
+                f += t * zn * (0.5 * t + ucand);
+                if (lane < iq) W.wsU[lane] = ua - t * ra;
+                ucand += t;
+                if (t == t2) { // full step: add the constraint (:392-426, add_constraint :450-513)
+                    if (iq >= QL) {
+                        status = STATUS_UNRESOLVED;
+                        done = true;
+                        break;
+                    }
+                    const double rho = sqrt(fmax(zn, 0.0));
+                    if (rho <= EPS * R_norm) {
+                        // degenerate: exclude ip, restore u, A (and x) of step 1, retry step 2
+                        const int bit = 4 * (kip >> 6) + eip;
+                        if (lane == (kip & 63)) exclm &= ~(1u << bit);
+                        wsync();
+                        if (lane < iq) {
+                            W.wsU[lane] = W.oldU[lane];
+                            W.wsP[lane] = W.oldP[lane];
+                            W.wsQ[lane] = W.oldQ[lane];
+                            W.wsRow[lane] = W.oldRow[lane];
+                            W.wsKS[lane] = W.oldKS[lane];
+                        }
+                        wsync();
+                        actm = 0;
+                        for (int a = 0; a < iq; a++) {
+                            const int ks = ufirst(W.wsKS[a]);
+                            if (lane == ((ks >> 2) & 63)) actm |= 1u << (4 * ((ks >> 2) >> 6) + (ks & 3));
+                        }
+                        pending = false;
+                        restart = true;
+                        break;
+                    }
+                    R_norm = fmax(R_norm, rho);
+                    const int off = tri(iq);
+                    if (lane < iq) {
+                        W.R[off + lane] = da;
+                        W.Rinv[off + lane] = -ra / rho;
+                    } else if (lane == iq) {
+                        W.R[off + iq] = rho;
+                        W.Rinv[off + iq] = 1.0 / rho;
+                        W.wsU[iq] = ucand;
+                        W.wsP[iq] = pip;
+                        W.wsQ[iq] = qip;
+                        W.wsRow[iq] = ipRow;
+                        W.wsKS[iq] = ipKS;
+                    }
+                    if (lane == (kip & 63)) actm |= 1u << (4 * (kip >> 6) + eip);
+                    iq++;
+                    pending = false;
+                    wsync();
+                    break; // goto l1
+                }
+                // partial step: drop the blocking constraint and try again (:434-446)
+                s_ip += t * zn;
+                {
+                    const int ksd = ufirst(W.wsKS[apos]);
+                    if (lane == ((ksd >> 2) & 63)) actm &= ~(1u << (4 * ((ksd >> 2) >> 6) + (ksd & 3)));
+                }
+                wsync();
+                drop_constraint(W, lane, iq, apos);
+            }
+        } while (restart);
+        if (done) break;
+    }
+
+    // ---- outputs -------------------------------------------------------------
+    const bool solved = status == MPCB_OK || status == MPCB_ITER_CAP;
+    if (lane == 0) {
+        if (out.cost) out.cost[inst] = f;
+        if (out.status) out.status[inst] = status;
+        if (out.iters) out.iters[inst] = iters;
+        if (out.n_active) out.n_active[inst] = iq;
+    }
+    if (out.active_idx || out.multipliers) {
+        for (int a = lane; a < out.active_stride; a += 64) {
+            const bool in_set = a < iq && a <= QL;
+            if (out.active_idx) out.active_idx[(size_t)inst * out.active_stride + a] = in_set ? W.wsRow[a] : -1;
+            if (out.multipliers) out.multipliers[(size_t)inst * out.active_stride + a] = in_set ? W.wsU[a] : 0.0;
+        }
+    }
+    // multipliers -> trajectories through the response matrices
+    int nresp = iq;
+    if (lane < iq) {
+        W.cx[lane] = W.wsU[lane] * W.wsP[lane];
+        W.cy[lane] = W.wsU[lane] * W.wsQ[lane];
+    }
+    if (pending && status == MPCB_ITER_CAP && iq < QL) {
+        if (lane == 0) {
+            W.cx[iq] = ucand * pip;
+            W.cy[iq] = ucand * qip;
+            W.wsKS[iq] = ipKS;
+        }
+        nresp = iq + 1;
+    }
+    wsync();
+    auto respond = [&](const double *K, const double *M, double *ox, double *oy) {
+        if (!ox && !oy) return;
+        double vx[NPL], vy[NPL];
+#pragma unroll
+        for (int c = 0; c < NPL; c++) {
+            const double *k4 = K + (size_t)kc[c] * 4;
+            vx[c] = k4[0] * wx[0] + k4[1] * wx[1] + k4[2] * wx[2] + k4[3] * wx[3];
+            vy[c] = k4[0] * wy[0] + k4[1] * wy[1] + k4[2] * wy[2] + k4[3] * wy[3];
+        }
+        for (int a = 0; a < nresp; a++) {
+            const int ka = ufirst(W.wsKS[a]) >> 2;
+            const double ca = W.cx[a], cb = W.cy[a];
+            const double *mrow = M + (size_t)ka * N;
+#pragma unroll
+            for (int c = 0; c < NPL; c++) {
+                const double mv = mrow[kc[c]];
+                vx[c] += ca * mv;
+                vy[c] += cb * mv;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NPL; c++)
+            if (kn[c] < N) {
+                if (ox) ox[(size_t)inst * N + kn[c]] = solved ? vx[c] : 0.0;
+                if (oy) oy[(size_t)inst * N + kn[c]] = solved ? vy[c] : 0.0;
+            }
+    };
+    respond(sd.Kx, sd.Wt, out.jerk_x, out.jerk_y);
+    respond(sd.Kc, sd.Sc, out.com_x, out.com_y);
+    respond(sd.Kv, sd.Sv, out.com_xd, out.com_yd);
+    if (out.zmp_x || out.zmp_y || out.min_margin) {
+        double vx[NPL], vy[NPL];
+#pragma unroll
+        for (int c = 0; c < NPL; c++) {
+            vx[c] = zxu[c];
+            vy[c] = zyu[c];
+        }
+        for (int a = 0; a < nresp; a++) {
+            const int ka = ufirst(W.wsKS[a]) >> 2;
+            const double ca = W.cx[a], cb = W.cy[a];
+            const double *srow = sd.S + (size_t)ka * N;
+#pragma unroll
+            for (int c = 0; c < NPL; c++) {
+                const double sv = srow[kc[c]];
+                vx[c] += ca * sv;
+                vy[c] += cb * sv;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NPL; c++)
+            if (kn[c] < N) {
+                if (out.zmp_x) out.zmp_x[(size_t)inst * N + kn[c]] = solved ? vx[c] : 0.0;
+                if (out.zmp_y) out.zmp_y[(size_t)inst * N + kn[c]] = solved ? vy[c] : 0.0;
+                if (out.min_margin) {
+                    // getConstraintViolation (MPCPlanner.cpp:1132-1153)
+                    double mn = DINF;
+#pragma unroll
+                    for (int e = 0; e < ES; e++)
+                        if (validm & (1u << (4 * c + e)))
+                            mn = fmin(mn, slotP(c, e) * vx[c] + slotQ(c, e) * vy[c] + slotR(c, e));
+                    out.min_margin[(size_t)inst * N + kn[c]] = solved ? mn : 0.0;
+                }
+            }
+    }
+}
+
+template <int NPL, bool POLY>
+hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
+                      hipStream_t stream) {
+    const size_t per_wave = sizeof(WaveState) + (POLY ? (size_t)sd.nphase * 12 * 8 : 0);
+    const size_t shmem = 4 * per_wave;
+    auto kfn = zspace_kernel<NPL, POLY>;
+    if (shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    const int blocks = (B + 3) / 4;
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), shmem, stream, sd, in, out, B);
+    return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launch_zspace(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
+                         hipStream_t stream) {
+    if (B <= 0) return hipSuccess;
+    const bool poly = sd.form != MPCB_BOX_1D;
+    const int npl = (sd.N + 63) / 64;
+    if (poly) {
+        if (npl <= 2) return launch_one<2, true>(sd, in, out, B, stream);
+        if (npl <= 4) return launch_one<4, true>(sd, in, out, B, stream);
+        return launch_one<8, true>(sd, in, out, B, stream);
+    }
+    if (npl <= 2) return launch_one<2, false>(sd, in, out, B, stream);
+    if (npl <= 4) return launch_one<4, false>(sd, in, out, B, stream);
+    return launch_one<8, false>(sd, in, out, B, stream);
+}
+
+} // namespace mpcb

@@ -1,0 +1,234 @@
+"""Python host side of the batched planner: a thin ctypes layer over the C ABI
+(``include/mpc_amd.h``) that keeps MPCPlanner's vocabulary (horizon, weights,
+footsteps, jerk/CoM/ZMP trajectories).  PyTorch only provides device memory and
+streams; every computation happens in ``libmpc_amd.so``.
+
+There is no CPU fallback: if the shared library or a GPU is missing, construction
+fails.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpc_amd.so")
+
+BOX_1D, COUPLED_JERK, COUPLED_VEL, COUPLED_REF, UNCONSTRAINED = 0, 1, 2, 3, 4
+OK, INFEASIBLE, ITER_CAP = 0, 1, 2
+
+# every symbol include/mpc_amd.h declares
+EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constraints",
+           "mpcb_solve_coupled_device", "mpcb_solve_coupled", "mpcb_solve_box_device",
+           "mpcb_solve_box", "mpcb_get_matrix")
+
+
+class Params(C.Structure):
+    _fields_ = [("horizon", C.c_int32), ("formulation", C.c_int32), ("Ts", C.c_double),
+                ("gravity", C.c_double), ("height", C.c_double), ("weight_R", C.c_double),
+                ("weight_Q", C.c_double), ("weight_Qs", C.c_double),
+                ("replanning_window", C.c_int32), ("number_of_steps", C.c_int32),
+                ("hip_offsets", C.c_double * 8), ("iter_cap", C.c_int32), ("device", C.c_int32)]
+
+
+class CoupledInputs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in
+                ("x0", "y0", "speed", "feet_x", "feet_y", "swing0", "com0")]
+
+
+_OUT_F64 = ("jerk_x", "jerk_y", "com_x", "com_y", "com_xd", "com_yd", "zmp_x", "zmp_y",
+            "min_margin", "cost")
+_OUT_I32 = ("status", "iters", "n_active", "active_idx")
+
+
+class Outputs(C.Structure):
+    _fields_ = ([(k, C.c_void_p) for k in _OUT_F64] + [(k, C.c_void_p) for k in _OUT_I32] +
+                [("multipliers", C.c_void_p), ("active_stride", C.c_int32)])
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libmpc_amd.so; raises if it is missing (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s not found: build it with `make -C mpc_amd/csrc` "
+                               "(or __graft_entry__.build())" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.mpcb_last_error.restype = C.c_char_p
+        lib.mpcb_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_void_p)]
+        lib.mpcb_destroy.argtypes = [C.c_void_p]
+        lib.mpcb_destroy.restype = None
+        lib.mpcb_num_constraints.argtypes = [C.c_void_p]
+        lib.mpcb_solve_coupled_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CoupledInputs),
+                                                  C.POINTER(Outputs), C.c_void_p]
+        lib.mpcb_solve_box_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.POINTER(Outputs), C.c_void_p]
+        lib.mpcb_get_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+class MpcError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc < 0:
+        raise MpcError("libmpc_amd error %d: %s" % (rc, load_library().mpcb_last_error().decode()))
+    return rc
+
+
+ALL_OUTPUTS = _OUT_F64 + _OUT_I32 + ("multipliers",)
+DEFAULT_OUTPUTS = ALL_OUTPUTS
+
+
+class BatchedPlanner:
+    """B independent MPCPlanner calls at once on one GPU.
+
+    Constructor arguments are those of ``MPCPlanner::MPCPlanner(horizon, Ts, gravity)``
+    (MPCPlanner.cpp:22), ``setWeights`` (:94-98) and the per-call scalars the reference
+    passes to its solve methods (height, replanning window, number of steps)."""
+
+    def __init__(self, horizon, Ts=0.1, gravity=9.81, formulation=COUPLED_VEL, height=0.5,
+                 weight_R=1e-6, weight_Q=1.0, weight_Qs=100.0, replanning_window=1000,
+                 number_of_steps=20, hip_offsets=None, iter_cap=0, device=0, active_stride=64):
+        import torch
+        self._torch = torch
+        lib = load_library()
+        p = Params()
+        p.horizon, p.formulation = int(horizon), int(formulation)
+        p.Ts, p.gravity, p.height = float(Ts), float(gravity), float(height)
+        p.weight_R, p.weight_Q, p.weight_Qs = float(weight_R), float(weight_Q), float(weight_Qs)
+        p.replanning_window, p.number_of_steps = int(replanning_window), int(number_of_steps)
+        hip = np.zeros(8) if hip_offsets is None else np.asarray(hip_offsets, dtype=np.float64).reshape(8)
+        for i in range(8):
+            p.hip_offsets[i] = float(hip[i])
+        p.iter_cap, p.device = int(iter_cap), int(device)
+        self.params = p
+        self.horizon = int(horizon)
+        self.formulation = int(formulation)
+        self.device = torch.device("cuda", int(device))
+        self.active_stride = int(active_stride)
+        h = C.c_void_p()
+        _check(lib.mpcb_create(C.byref(p), C.byref(h)))
+        self._h = h
+        self.num_constraints = lib.mpcb_num_constraints(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().mpcb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ---------------------------------------------------------------
+    def _dev(self, a, dtype):
+        torch = self._torch
+        if a is None:
+            return None
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=dtype)
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=self.device)
+        return t.contiguous()
+
+    def _alloc_outputs(self, B, outputs):
+        torch = self._torch
+        N = self.horizon
+        res, o = {}, Outputs()
+        o.active_stride = self.active_stride
+        for name in ALL_OUTPUTS:
+            if name not in outputs:
+                continue
+            if name in ("cost",):
+                t = torch.empty(B, dtype=torch.float64, device=self.device)
+            elif name in ("status", "iters", "n_active"):
+                t = torch.empty(B, dtype=torch.int32, device=self.device)
+            elif name == "active_idx":
+                t = torch.empty((B, self.active_stride), dtype=torch.int32, device=self.device)
+            elif name == "multipliers":
+                t = torch.empty((B, self.active_stride), dtype=torch.float64, device=self.device)
+            else:
+                t = torch.empty((B, N), dtype=torch.float64, device=self.device)
+            res[name] = t
+            setattr(o, name, t.data_ptr())
+        return res, o
+
+    def _stream(self, stream):
+        if stream is None:
+            stream = self._torch.cuda.current_stream(self.device)
+        return C.c_void_p(stream.cuda_stream)
+
+    def matrix(self, which):
+        """Instance-independent tables (0 S, 1 W^T, 2 CoM, 3 CoM velocity: N x N;
+        4 Kz, 5 Kx: N x 4)."""
+        N = self.horizon
+        out = np.zeros((N, N if which < 4 else 4))
+        _check(load_library().mpcb_get_matrix(self._h, which, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # -- solves ----------------------------------------------------------------
+    def prepare_coupled(self, x0, y0, speed, feet_x, feet_y, swing0, com0=None):
+        """Uploads one batch of coupled inputs; returns an opaque (B, struct, keepalive)."""
+        f64, i32 = self._torch.float64, self._torch.int32
+        ts = dict(x0=self._dev(x0, f64), y0=self._dev(y0, f64), speed=self._dev(speed, f64),
+                  feet_x=self._dev(feet_x, f64), feet_y=self._dev(feet_y, f64),
+                  swing0=self._dev(swing0, i32), com0=self._dev(com0, f64))
+        B = ts["x0"].shape[0]
+        shapes = dict(x0=(B, 3), y0=(B, 3), speed=(B, 2), feet_x=(B, 4), feet_y=(B, 4),
+                      swing0=(B,), com0=(B, 2))
+        ci = CoupledInputs()
+        for k, t in ts.items():
+            if t is None:
+                continue
+            if tuple(t.shape) != shapes[k]:
+                raise ValueError("%s must have shape %s, got %s" % (k, shapes[k], tuple(t.shape)))
+            setattr(ci, k, t.data_ptr())
+        return B, ci, ts
+
+    def solve_coupled_prepared(self, prepared, outputs=DEFAULT_OUTPUTS, out=None, stream=None):
+        B, ci, _ = prepared
+        if out is None:
+            out = self._alloc_outputs(B, outputs)
+        res, o = out
+        _check(load_library().mpcb_solve_coupled_device(self._h, B, C.byref(ci), C.byref(o),
+                                                        self._stream(stream)))
+        return res
+
+    def solve_coupled(self, x0, y0, speed, feet_x, feet_y, swing0, com0=None,
+                      outputs=DEFAULT_OUTPUTS, stream=None):
+        """computeSteps + solveQPConstraintCoupled + trajectory read-out for B instances.
+        Returns a dict of device tensors (asynchronous on `stream`)."""
+        prepared = self.prepare_coupled(x0, y0, speed, feet_x, feet_y, swing0, com0)
+        return self.solve_coupled_prepared(prepared, outputs=outputs, stream=stream)
+
+    def prepare_box(self, x0, zmin, zmax):
+        f64 = self._torch.float64
+        ts = (self._dev(x0, f64), self._dev(zmin, f64), self._dev(zmax, f64))
+        B = ts[0].shape[0]
+        if tuple(ts[0].shape) != (B, 3) or tuple(ts[1].shape) != (B, self.horizon) or \
+                tuple(ts[2].shape) != (B, self.horizon):
+            raise ValueError("x0 must be [B,3]; zmin, zmax must be [B,horizon]")
+        return B, ts
+
+    def solve_box_prepared(self, prepared, outputs=DEFAULT_OUTPUTS, out=None, stream=None):
+        B, ts = prepared
+        if out is None:
+            out = self._alloc_outputs(B, outputs)
+        res, o = out
+        _check(load_library().mpcb_solve_box_device(self._h, B, ts[0].data_ptr(), ts[1].data_ptr(),
+                                                    ts[2].data_ptr(), C.byref(o),
+                                                    self._stream(stream)))
+        return res
+
+    def solve_box(self, x0, zmin, zmax, outputs=DEFAULT_OUTPUTS, stream=None):
+        """solveQPconstraint for B one-axis instances; results are in the *_x outputs."""
+        return self.solve_box_prepared(self.prepare_box(x0, zmin, zmax), outputs=outputs,
+                                       stream=stream)

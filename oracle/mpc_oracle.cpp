@@ -371,6 +371,10 @@ l2: /* :279-292 */
 
 l2a: /* :306-311  d = J^T np ; z = J2 d2 ; r = R^{-1} d1 */
     w.n_l2a++;
+    if (iter_cap > 0 && w.n_l2a > iter_cap) {
+        status = ORC_ITER_CAP;
+        goto done;
+    }
     w.falg += 2.0 * n * (double)n + 2.0 * n * (double)(n - iq) + (double)iq * iq;
     for (int j = 0; j < n; j++) d[j] = dot(J.col(j), np.data(), n);
     std::fill(z.begin(), z.end(), 0.0);

@@ -42,7 +42,9 @@ typedef struct {
                           reference's dense Eigen products do (honest CPU
                           baseline); 0: skip exact-zero multiplicands (same
                           values, several times faster; used by tests)      */
-    int    iter_cap;   /* cap on l1 passes (the reference has none); <=0: none */
+    int    iter_cap;   /* cap on l1 passes and on step-direction (l2a) passes; the
+                          reference has none and can cycle on infeasible problems;
+                          <=0: none */
 } orc_params;
 
 typedef struct {
