@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched CoM-MPC QP path on MI355X.
+
+One "step" = one pass of the hot path (footstep rollout -> polygon rows -> QP solve ->
+trajectory read-out) over one batch whose inputs already sit in HBM.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workloads (--workload):
+  coupled_vel  (default) 8,192 coupled-XY instances per GPU, N=200 knots, 20 steps, n=400
+               variables, m=700 polygon rows, velocity formulation R=0.01 Q=1 (constraints
+               bind).  At 8 GPUs this is the 65,536-instance batch.
+  coupled_jerk same shape, jerk-only formulation.
+  decoupled    4,096 X/Y pairs of box-constrained 1-D QPs per GPU, N=100, m=200 per axis.
+
+Instances are independent, so rank r solves instances [r*B, (r+1)*B) of one global batch
+and nothing is exchanged during a step (weak scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from mpc_amd import batches, planner as P  # noqa: E402
+
+# fp64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) per clock at the
+# 2.4 GHz maximum clock of MI355X_MICROARCH's chip table.
+FP64_FLOP_PER_CLK_PER_CU = 128
+HBM_PEAK_GBS = 8000.0
+
+
+def fp64_vector_peak_tflops(dev):
+    props = torch.cuda.get_device_properties(dev)
+    cus = props.multi_processor_count
+    clock_hz = getattr(props, "clock_rate", 2400000) * 1e3  # kHz -> Hz
+    if clock_hz <= 0:
+        clock_hz = 2.4e9
+    return cus * clock_hz * FP64_FLOP_PER_CLK_PER_CU / 1e12, cus, clock_hz
+
+
+class CoupledWorkload:
+    unit = "solves/s"
+
+    def __init__(self, form, B, first, dev):
+        self.N, self.steps_per_plan = 200, 20
+        self.B = B
+        self.form = form
+        self.name = "coupled_vel" if form == P.COUPLED_VEL else "coupled_jerk"
+        self.inputs = batches.coupled_batch(B, first=first)
+        self.pl = P.BatchedPlanner(self.N, formulation=form, weight_R=0.01, weight_Q=1.0,
+                                   number_of_steps=self.steps_per_plan, device=dev)
+        self.prepared = self.pl.prepare_coupled(**self.inputs)
+        self.out = self.pl._alloc_outputs(B, P.ALL_OUTPUTS)
+        self.units = B
+        self.launches = 1
+        # algorithmic bytes per instance: 25 input doubles + 6N+2 output doubles + ints
+        self.alg_bytes = B * (8 * (25 + 6 * self.N + 2) + 4 * (self.pl.active_stride + 4))
+
+    def step(self):
+        self.pl.solve_coupled_prepared(self.prepared, out=self.out)
+
+    def results(self):
+        return self.out[0]
+
+    def alg_flops(self):
+        return float(self.out[0]["alg_flops"].sum().item())
+
+    def describe(self):
+        return {"workload": self.name, "instances_per_gpu": self.B, "horizon": self.N,
+                "number_of_steps": 20, "variables": 400, "constraints": self.pl.num_constraints,
+                "weights": {"R": 0.01, "Q": 1.0}, "seed": batches.SEED}
+
+    def cpu_baseline(self, threads, sample):
+        from oracle import oracle as O
+        p = O.params(self.N, R=0.01, Q=1.0, Qs=100.0, height=0.5, dense=1, iter_cap=0)
+        oform = O.COUPLED_VEL if self.form == P.COUPLED_VEL else O.COUPLED_JERK
+        i = self.inputs
+        t = time.perf_counter()
+        ref = O.coupled_batch(p, oform, self.steps_per_plan, 1000, i["x0"][:sample], i["y0"][:sample],
+                              i["speed"][:sample], i["feet_x"][:sample], i["feet_y"][:sample],
+                              i["swing0"][:sample], nthreads=threads)
+        dt = time.perf_counter() - t
+        return sample / dt, ref
+
+
+class DecoupledWorkload:
+    unit = "solves/s"
+
+    def __init__(self, B, first, dev):
+        self.N = 100
+        self.B = B
+        self.name = "decoupled"
+        self.inputs = batches.decoupled_batch(B, N=self.N, steps=10, first=first)
+        self.pl = P.BatchedPlanner(self.N, formulation=P.BOX_1D, weight_R=1.0, device=dev)
+        i = self.inputs
+        self.px = self.pl.prepare_box(i["x0"], i["xmin"], i["xmax"])
+        self.py = self.pl.prepare_box(i["y0"], i["ymin"], i["ymax"])
+        self.outx = self.pl._alloc_outputs(B, P.ALL_OUTPUTS)
+        self.outy = self.pl._alloc_outputs(B, P.ALL_OUTPUTS)
+        self.units = B  # one unit = one X/Y pair (two scalar QPs)
+        self.launches = 2
+        self.alg_bytes = 2 * B * (8 * (3 + 2 * self.N + 2 * self.N + 1) + 4 * (self.pl.active_stride + 4))
+
+    def step(self):
+        self.pl.solve_box_prepared(self.px, out=self.outx)
+        self.pl.solve_box_prepared(self.py, out=self.outy)
+
+    def results(self):
+        return self.outy[0]
+
+    def alg_flops(self):
+        return float(self.outx[0]["alg_flops"].sum().item() + self.outy[0]["alg_flops"].sum().item())
+
+    def describe(self):
+        return {"workload": self.name, "xy_pairs_per_gpu": self.B, "horizon": self.N,
+                "variables": 100, "constraints": 200, "weights": {"R": 1.0}, "seed": batches.SEED}
+
+    def cpu_baseline(self, threads, sample):
+        from oracle import oracle as O
+        p = O.params(self.N, R=1.0, height=0.5, dense=1, iter_cap=3000)
+        i = self.inputs
+        t = time.perf_counter()
+        ref = O.box_batch(p, i["x0"][:sample], i["y0"][:sample], i["xmin"][:sample], i["xmax"][:sample],
+                          i["ymin"][:sample], i["ymax"][:sample], nthreads=threads)
+        dt = time.perf_counter() - t
+        return sample / dt, ref
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="coupled_vel",
+                    choices=("coupled_vel", "coupled_jerk", "decoupled"))
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (0 = workload default)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="instances timed on the host cores (0 disables, -1 = default)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = local if distributed else 0
+    torch.cuda.set_device(dev)
+
+    if args.workload == "decoupled":
+        B = args.batch or 4096
+        wl = DecoupledWorkload(B, rank * B, dev)
+    else:
+        B = args.batch or 8192
+        form = P.COUPLED_VEL if args.workload == "coupled_vel" else P.COUPLED_JERK
+        wl = CoupledWorkload(form, B, rank * B, dev)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        wl.step()
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    dev_ms = ev0.elapsed_time(ev1)  # device time of the K steps on the launch stream
+    if distributed:
+        tt = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms = tt[0].item(), tt[1].item()
+
+    res = wl.results()
+    status = res["status"].cpu().numpy()
+    n_active = res["n_active"].cpu().numpy()
+    iters = res["iters"].cpu().numpy()
+    alg_flops = wl.alg_flops()
+
+    if rank == 0:
+        peak_tf, cus, clk = fp64_vector_peak_tflops(dev)
+        kernel_s = dev_ms / 1e3 / (args.steps * wl.launches)  # average launch duration
+        achieved_tf = alg_flops / wl.launches / kernel_s / 1e12
+        value = wl.units * world / (elapsed / args.steps)
+        line = {
+            "metric": "constrained CoM QP solves/sec",
+            "value": value,
+            "unit": wl.unit,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": wl.describe(),
+            "roofline": {
+                "bound": "fp64_vector",
+                "achieved": achieved_tf,
+                "peak": peak_tf,
+                "unit": "TFLOP/s",
+                "frac": achieved_tf / peak_tf,
+                "traffic": None,
+                "note": "achieved = operations of the dense dual active-set method along each "
+                        "instance's pivot sequence / average kernel duration; the kernel executes "
+                        "far fewer operations than that (structure-exploiting formulation)",
+                "kernel_ms": kernel_s * 1e3,
+                "alg_gflop_per_launch": alg_flops / wl.launches / 1e9,
+                "hbm_achieved_GBs": wl.alg_bytes / wl.launches / kernel_s / 1e9,
+                "hbm_frac": wl.alg_bytes / wl.launches / kernel_s / 1e9 / HBM_PEAK_GBS,
+                "peak_basis": "%d CUs x %.2f GHz x %d fp64 flop/clk/CU" % (cus, clk / 1e9,
+                                                                         FP64_FLOP_PER_CLK_PER_CU),
+            },
+            "solver": {
+                "status_counts": np.bincount(status, minlength=4).tolist(),
+                "working_set_mean": float(n_active.mean()),
+                "working_set_max": int(n_active.max()),
+                "outer_iterations_mean": float(iters.mean()),
+            },
+        }
+        sample = args.cpu_sample
+        if sample < 0:
+            sample = 192 if args.workload != "decoupled" else 2048
+        if world == 1 and sample > 0:
+            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            sample = min(sample, wl.B)
+            rate, _ = wl.cpu_baseline(threads, sample)
+            line["cpu_baseline"] = {
+                "value": rate, "unit": wl.unit, "cores": threads, "kind": "port",
+                "sample": "first %d instances of the same batch, dense restatement of "
+                          "MPCPlanner + eiquadprog (oracle, dense=1), one planner per thread" % sample,
+                "per_core": rate / threads,
+            }
+            line["speedup_vs_cpu_baseline"] = value / rate
+        print(json.dumps(line))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,6 +107,10 @@ typedef struct {
                                           set in the order the solver holds them, -1 padded */
     double  *multipliers;       /* [B][active_stride] their Lagrange multipliers          */
     int32_t  active_stride;
+    double  *alg_flops;         /* [B]    diagnostic: floating-point operations the dense
+                                          dual active-set method (eiquadprog.hpp) spends along
+                                          this instance's pivot sequence; used for roofline
+                                          reporting, not a count of what the GPU executed      */
 } mpcb_outputs;
 
 /* Builds every instance-independent matrix (prediction matrices, condensed

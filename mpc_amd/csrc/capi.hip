@@ -101,6 +101,7 @@ int stage_outputs(Staging &st, const mpcb_outputs &h, mpcb_outputs &d, size_t B,
     OUT_(com_xd, B * N) OUT_(com_yd, B * N) OUT_(zmp_x, B * N) OUT_(zmp_y, B * N)
     OUT_(min_margin, B * N) OUT_(cost, B) OUT_(status, B) OUT_(iters, B) OUT_(n_active, B)
     OUT_(active_idx, B * (size_t)h.active_stride) OUT_(multipliers, B * (size_t)h.active_stride)
+    OUT_(alg_flops, B)
 #undef OUT_
     return 0;
 }
@@ -113,6 +114,7 @@ int fetch_outputs(const mpcb_outputs &h, const mpcb_outputs &d, size_t B, size_t
     BACK_(com_xd, B * N) BACK_(com_yd, B * N) BACK_(zmp_x, B * N) BACK_(zmp_y, B * N)
     BACK_(min_margin, B * N) BACK_(cost, B) BACK_(status, B) BACK_(iters, B) BACK_(n_active, B)
     BACK_(active_idx, B * (size_t)h.active_stride) BACK_(multipliers, B * (size_t)h.active_stride)
+    BACK_(alg_flops, B)
 #undef BACK_
     return 0;
 }

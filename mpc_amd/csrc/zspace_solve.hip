@@ -401,6 +401,9 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
 
     // ---- dual active-set loop ----------------------------------------------
     int iq = 0, iters = 0, passes = 0, status = MPCB_OK;
+    // operation count of the dense method along this pivot sequence (diagnostic)
+    const double nn = (double)(N * (POLY ? 2 : 1)), mm = (double)sd.m;
+    double falg = 2.0 * nn * nn;
     unsigned actm = 0, exclm = 0;
     double R_norm = 1.0;
     double s[NPL][ES], zx[NPL], zy[NPL];
@@ -447,6 +450,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                 psi += fmin(0.0, v);
             }
         psi = wave_sum(psi);
+        falg += 2.0 * mm * nn;
         exclm = 0xffffffffu; // iaexcl[i] = true (:257)
         if (fabs(psi) <= sd.psi_thr) break; // :267-272
         if (lane < iq) { // :275-277
@@ -506,6 +510,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                     done = true;
                     break;
                 }
+                falg += 2.0 * nn * nn + 2.0 * nn * (nn - iq) + (double)iq * iq;
                 // g = N_A' G^-1 n_ip ; d = R^-T g (= J1' n_ip) ; r = R^-1 d
                 double ga = 0.0, da = 0.0, ra = 0.0, ua = 0.0;
                 if (lane < iq) {
@@ -591,6 +596,10 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                     const int ksd = ufirst(W.wsKS[apos]);
                     if (lane == ((ksd >> 2) & 63)) actm &= ~(1u << (4 * ((ksd >> 2) >> 6) + (ksd & 3)));
                     wsync();
+                    {
+                        const double cdrop = (double)(iq - 1 - apos);
+                        falg += 6.0 * nn * cdrop + 3.0 * cdrop * (cdrop - 1.0);
+                    }
                     drop_constraint(W, lane, iq, apos);
                     continue;
                 }
@@ -604,6 +613,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                         done = true;
                         break;
                     }
+                    falg += 6.0 * nn * (nn - iq - 1);
                     const double rho = sqrt(fmax(zn, 0.0));
                     if (rho <= EPS * R_norm) {
                         // degenerate: exclude ip, restore u, A (and x) of step 1, retry step 2
@@ -654,6 +664,10 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                     if (lane == ((ksd >> 2) & 63)) actm &= ~(1u << (4 * ((ksd >> 2) >> 6) + (ksd & 3)));
                 }
                 wsync();
+                {
+                    const double cdrop = (double)(iq - 1 - apos);
+                    falg += 6.0 * nn * cdrop + 3.0 * cdrop * (cdrop - 1.0);
+                }
                 drop_constraint(W, lane, iq, apos);
             }
         } while (restart);
@@ -667,6 +681,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
         if (out.status) out.status[inst] = status;
         if (out.iters) out.iters[inst] = iters;
         if (out.n_active) out.n_active[inst] = iq;
+        if (out.alg_flops) out.alg_flops[inst] = falg + (POLY ? 2.0 * mm * nn : 0.0);
     }
     if (out.active_idx || out.multipliers) {
         for (int a = lane; a < out.active_stride; a += 64) {

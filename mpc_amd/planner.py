@@ -43,7 +43,8 @@ _OUT_I32 = ("status", "iters", "n_active", "active_idx")
 
 class Outputs(C.Structure):
     _fields_ = ([(k, C.c_void_p) for k in _OUT_F64] + [(k, C.c_void_p) for k in _OUT_I32] +
-                [("multipliers", C.c_void_p), ("active_stride", C.c_int32)])
+                [("multipliers", C.c_void_p), ("active_stride", C.c_int32),
+                 ("alg_flops", C.c_void_p)])
 
 
 _lib = None
@@ -81,7 +82,7 @@ def _check(rc):
     return rc
 
 
-ALL_OUTPUTS = _OUT_F64 + _OUT_I32 + ("multipliers",)
+ALL_OUTPUTS = _OUT_F64 + _OUT_I32 + ("multipliers", "alg_flops")
 DEFAULT_OUTPUTS = ALL_OUTPUTS
 
 
@@ -147,7 +148,7 @@ class BatchedPlanner:
         for name in ALL_OUTPUTS:
             if name not in outputs:
                 continue
-            if name in ("cost",):
+            if name in ("cost", "alg_flops"):
                 t = torch.empty(B, dtype=torch.float64, device=self.device)
             elif name in ("status", "iters", "n_active"):
                 t = torch.empty(B, dtype=torch.int32, device=self.device)

@@ -1,0 +1,171 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on identical inputs:
+CoM/ZMP/jerk trajectories and objective within 1e-6 relative, identical working sets,
+identical status; plus oracle-free properties at full batch size."""
+import numpy as np
+import pytest
+
+from mpc_amd import batches
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6  # tolerance stated by the project's north star for trajectories and objective
+
+
+@pytest.fixture(scope="module")
+def P():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from mpc_amd import planner
+    planner.load_library()
+    return planner
+
+
+def _np(out):
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+def _check_coupled(o, ref, B):
+    assert (o["status"] == ref["status"]).all()
+    assert (o["iters"] == ref["iters"]).all()
+    for i in range(B):
+        na = ref["n_active"][i]
+        assert o["n_active"][i] == na
+        assert list(o["active_idx"][i, :na]) == list(ref["active"][i, :na])
+        assert (o["active_idx"][i, na:] == -1).all()
+        for k in ("jerk_x", "jerk_y", "com_x", "com_y", "zmp_x", "zmp_y"):
+            assert _rel(o[k][i], ref[k][i]) < RTOL, (k, i)
+    assert (np.abs(o["cost"] - ref["cost"]) <= RTOL * np.abs(ref["cost"])).all()
+    assert np.abs(o["min_margin"] - ref["viol_knot"]).max() < 1e-8
+    assert np.allclose(o["alg_flops"], ref["falg"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("form_name,R", [("COUPLED_VEL", 0.01), ("COUPLED_JERK", 0.01),
+                                         ("COUPLED_VEL", 1e-6)])
+def test_coupled_full_size_vs_oracle(P, oracle, form_name, R):
+    B, N, steps = 96, 200, 20
+    bt = batches.coupled_batch(B)
+    form = getattr(P, form_name)
+    pl = P.BatchedPlanner(N, formulation=form, weight_R=R, weight_Q=1.0, number_of_steps=steps)
+    o = _np(pl.solve_coupled(**bt))
+    ref = oracle.coupled_batch(oracle.params(N, R=R, Q=1.0, height=0.5, iter_cap=4000),
+                               getattr(oracle, form_name), steps, 1000, bt["x0"], bt["y0"], bt["speed"],
+                               bt["feet_x"], bt["feet_y"], bt["swing0"], nthreads=16)
+    _check_coupled(o, ref, B)
+    if form_name == "COUPLED_VEL" and R == 0.01:
+        assert ref["n_active"].min() >= 1  # this batch is the one where constraints bind
+
+
+@pytest.mark.parametrize("N,steps,rw", [(60, 6, 1000), (100, 10, 10), (130, 7, 1000), (64, 8, 5)])
+def test_coupled_other_shapes_vs_oracle(P, oracle, N, steps, rw):
+    """Ragged horizons (trailing 4-stance knots), Gaussian velocity weights, odd step lengths."""
+    B = 24
+    bt = batches.coupled_batch(B, first=1000)
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0,
+                          replanning_window=rw, number_of_steps=steps)
+    o = _np(pl.solve_coupled(**bt))
+    ref = oracle.coupled_batch(oracle.params(N, R=0.01, Q=1.0, height=0.5, iter_cap=4000), oracle.COUPLED_VEL,
+                               steps, rw, bt["x0"], bt["y0"], bt["speed"], bt["feet_x"], bt["feet_y"],
+                               bt["swing0"], nthreads=16)
+    _check_coupled(o, ref, B)
+
+
+def test_coupled_com_step_correction(P, oracle):
+    """computeSteps with an initial CoM (MPCPlanner.cpp:1231-1238, 1266-1283)."""
+    B, N, steps = 16, 200, 20
+    bt = batches.coupled_batch(B, first=5000)
+    bt["com0"] = np.stack([bt["x0"][:, 0] + 0.01, bt["y0"][:, 0] - 0.01], axis=1)
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, replanning_window=10,
+                          number_of_steps=steps)
+    o = _np(pl.solve_coupled(**bt))
+    ref = oracle.coupled_batch(oracle.params(N, R=0.01, Q=1.0, height=0.5, iter_cap=4000), oracle.COUPLED_VEL,
+                               steps, 10, bt["x0"], bt["y0"], bt["speed"], bt["feet_x"], bt["feet_y"],
+                               bt["swing0"], com0=bt["com0"], nthreads=16)
+    _check_coupled(o, ref, B)
+
+
+def test_box_vs_oracle(P, oracle):
+    B, N = 128, 100
+    bt = batches.decoupled_batch(B)
+    pl = P.BatchedPlanner(N, formulation=P.BOX_1D, weight_R=1.0)
+    ref = oracle.box_batch(oracle.params(N, R=1.0, height=0.5, iter_cap=3000), bt["x0"], bt["y0"], bt["xmin"],
+                           bt["xmax"], bt["ymin"], bt["ymax"], nthreads=16)
+    for ax, (s0, lo, hi, jr) in enumerate(((bt["x0"], bt["xmin"], bt["xmax"], ref["jerk_x"]),
+                                           (bt["y0"], bt["ymin"], bt["ymax"], ref["jerk_y"]))):
+        o = _np(pl.solve_box(s0, lo, hi))
+        assert (o["status"] == ref["status"][:, ax]).all()
+        ok = ref["status"][:, ax] == 0
+        assert ok.sum() > B // 2
+        assert (o["iters"][ok] == ref["iters"][ok, ax]).all()
+        for i in np.nonzero(ok)[0]:
+            na = ref["n_active"][i, ax]
+            assert list(o["active_idx"][i, :o["n_active"][i]]) == list(ref["active"][i, ax, :na])
+            assert _rel(o["jerk_x"][i], jr[i]) < RTOL
+            # the ZMP honours the box
+            assert (o["zmp_x"][i] >= lo[i] - 1e-9).all() and (o["zmp_x"][i] <= hi[i] + 1e-9).all()
+        assert (np.abs(o["cost"][ok] - ref["cost"][ok, ax]) <= RTOL * np.maximum(1e-12, np.abs(ref["cost"][ok, ax]))).all()
+        # infeasible draws: zero-filled outputs, infinite cost
+        bad = ~ok
+        if bad.any():
+            assert np.isinf(o["cost"][bad]).all() and (o["jerk_x"][bad] == 0).all()
+
+
+def test_default_driver_scenarios(P):
+    """The recorded outputs of the reference's two default drivers, through the GPU path."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_recorded.json")))
+    g = gold["decoupled_default"]
+    xmin, xmax, ymin, ymax = batches.box_limits(100, 10, 3.0, 0.2)
+    pl = P.BatchedPlanner(100, formulation=P.BOX_1D, weight_R=1.0)
+    oy = _np(pl.solve_box(np.zeros((1, 3)), ymin, ymax))
+    ox = _np(pl.solve_box(np.zeros((1, 3)), xmin, xmax))
+    assert np.allclose(oy["jerk_x"][0, :3], g["jerk_y_0_2"], rtol=2e-6)
+    ay, ax = oy["active_idx"][0, :oy["n_active"][0]], ox["active_idx"][0, :ox["n_active"][0]]
+    assert [(ay >= 100).sum(), (ay < 100).sum()] == g["y_active_upper_lower"]
+    assert [(ax >= 100).sum(), (ax < 100).sum()] == g["x_active_upper_lower"]
+
+
+def test_full_batch_properties(P):
+    """8,192 instances (one GPU's share of the 65,536 batch): properties that need no oracle."""
+    B, N = 8192, 200
+    bt = batches.coupled_batch(B)
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=20)
+    o = _np(pl.solve_coupled(**bt))
+    assert (o["status"] == 0).all()
+    # primal feasibility and complementarity: margins >= 0, active rows sit on their edge
+    assert o["min_margin"].min() > -1e-9
+    assert (o["multipliers"] >= -1e-9).all()
+    # ZMP = CoM - h/g * acceleration; check through the integrator on a sample
+    Ts, h, g = 0.1, 0.5, 9.81
+    for i in range(0, B, 1024):
+        st = bt["x0"][i].copy()
+        for k in range(N):
+            u = o["jerk_x"][i, k]
+            st = np.array([st[0] + Ts * st[1] + Ts ** 2 / 2 * st[2] + Ts ** 3 / 6 * u,
+                           st[1] + Ts * st[2] + Ts ** 2 / 2 * u, st[2] + Ts * u])
+            assert abs(st[0] - o["com_x"][i, k]) < 1e-9
+            assert abs(st[1] - o["com_xd"][i, k]) < 1e-9
+            assert abs(st[0] - h / g * st[2] - o["zmp_x"][i, k]) < 1e-9
+    # determinism: a second launch returns the same bits
+    o2 = _np(pl.solve_coupled(**bt))
+    for k in ("jerk_x", "cost", "active_idx"):
+        assert np.array_equal(o[k], o2[k])
+    # a slice of the batch solved alone gives the same bits (instances are independent)
+    sl = {k: v[4000:4032] for k, v in bt.items()}
+    o3 = _np(pl.solve_coupled(**sl))
+    assert np.array_equal(o3["jerk_x"], o["jerk_x"][4000:4032])
+
+
+def test_empty_batch_and_bad_arguments(P):
+    pl = P.BatchedPlanner(20, formulation=P.BOX_1D, weight_R=1.0)
+    out = pl.solve_box(np.zeros((0, 3)), np.zeros((0, 20)), np.zeros((0, 20)))
+    assert out["jerk_x"].shape == (0, 20)
+    with pytest.raises(ValueError):
+        pl.solve_box(np.zeros((2, 3)), np.zeros((2, 19)), np.zeros((2, 20)))
+    with pytest.raises(P.MpcError):
+        P.BatchedPlanner(0, formulation=P.BOX_1D)
+    with pytest.raises(P.MpcError):
+        P.BatchedPlanner(200, formulation=P.COUPLED_VEL, number_of_steps=0)

@@ -1,0 +1,241 @@
+"""The CPU oracle against everything the reference offers to pin it:
+the known-answer comment in tests/unconstrainedQP/testPlanner.cpp:57, the recorded
+6-digit outputs of the two default driver scenarios, closed forms, the MATLAB
+helper semantics, KKT residuals and an independent scipy solve."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_zmp_known_answer(oracle):
+    # testPlanner.cpp:57 ("from matlab"); inputs inferred: x0=(0.1,-0.1,0), jerk=1, N=10
+    kat = np.array([0.08507, 0.07114, 0.059209, 0.050279, 0.045349, 0.045419, 0.051489,
+                    0.064559, 0.085628, 0.1157])
+    z = oracle.trajectory(oracle.params(10), 3, [0.1, -0.1, 0.0], np.ones(10))
+    assert np.abs(z - kat).max() < 2e-6
+
+
+def test_build_matrix_closed_forms(oracle):
+    # MPCPlanner.cpp:101-156: A^k closed form, Toeplitz first columns
+    N, T, h, g = 50, 0.1, 0.5, 9.81
+    p = oracle.params(N, Ts=T, g=g, height=h)
+    k = np.arange(N)
+    for which, col in ((0, T ** 3 * (1 + 3 * k + 3 * k ** 2) / 6), (1, T ** 2 * (1 + 2 * k) / 2),
+                       (2, np.full(N, T))):
+        sx, su = oracle.build_matrix(p, which)
+        assert np.allclose(su[:, 0], col, rtol=1e-12)
+        assert np.allclose(su, np.tril(su))
+        for d in range(N):  # Toeplitz
+            assert np.allclose(np.diag(su, -d), col[d], rtol=1e-12)
+    zx, zu = oracle.build_matrix(p, 3)
+    xpx, xpu = oracle.build_matrix(p, 0)
+    xax, xau = oracle.build_matrix(p, 2)
+    assert np.allclose(zu, xpu - h / g * xau, rtol=1e-12, atol=1e-15)
+    i = np.arange(1, N + 1) * T
+    assert np.allclose(xpx, np.stack([np.ones(N), i, i * i / 2], axis=1), rtol=1e-12)
+
+
+def test_trajectory_is_the_integrator(oracle):
+    # tests/computeDynamics.m:11-15 and computeCOMupdate (MPCPlanner.cpp:1155-1158)
+    p = oracle.params(30)
+    rng = np.random.default_rng(0)
+    jerk = rng.normal(size=30)
+    st = np.array([0.1, -0.2, 0.3])
+    pos = oracle.trajectory(p, 0, st, jerk)
+    vel = oracle.trajectory(p, 1, st, jerk)
+    zmp = oracle.trajectory(p, 3, st, jerk)
+    for k in range(30):
+        st = oracle.com_update(p, st, jerk[k])
+        assert abs(st[0] - pos[k]) < 1e-12 and abs(st[1] - vel[k]) < 1e-12
+        assert abs(st[0] - 0.5 / 9.81 * st[2] - zmp[k]) < 1e-12
+
+
+def test_point_right_of_line_and_ccw_sort(oracle):
+    # planning.h:143-149; tests/Point2isRightOfLine.m:7
+    assert oracle.point2_is_right_of_line([0, 0], [1, 0], [0.5, -1]) > 0
+    assert oracle.point2_is_right_of_line([0, 0], [1, 0], [0.5, 1]) < 0
+    assert oracle.point2_is_right_of_line([0, 0], [1, 0], [2, 0]) == 0
+    # planning.h:182-197: pivot is the FIRST point, order becomes counter-clockwise
+    feet = np.array([[0.1, 1.0], [0.2, -1.0], [-0.4, 1.0], [-0.3, -1.0]])  # LF RF LH RH
+    s = oracle.ccw_sort(feet)
+    assert np.allclose(s[0], feet[0])
+    area = 0.5 * sum(s[i, 0] * s[(i + 1) % 4, 1] - s[(i + 1) % 4, 0] * s[i, 1] for i in range(4))
+    assert area > 0
+    # mirror of tests/clockWiseSort.m:15-25 with the opposite sign
+    cw = feet.copy()
+    for i in range(1, 3):
+        for j in range(i + 1, 4):
+            if oracle.point2_is_right_of_line(cw[0], cw[i], cw[j]) < 0:
+                cw[[i, j]] = cw[[j, i]]
+    assert np.allclose(cw[1:][::-1], s[1:])
+
+
+def test_line_coeff(oracle):
+    # planning.h:236-260: interior of a CCW polygon has p*x + q*y + r > 0
+    feet = oracle.ccw_sort(np.array([[0.1, 1.0], [0.2, -1.0], [-0.4, 1.0], [-0.3, -1.0]]))
+    c = feet.mean(axis=0)
+    for e in range(4):
+        p, q, r = oracle.line_coeff(feet[e], feet[(e + 1) % 4])
+        assert abs(np.hypot(p, q) - 1) < 1e-15
+        assert abs(p * feet[e, 0] + q * feet[e, 1] + r) < 1e-15
+        assert p * c[0] + q * c[1] + r > 0
+    p, q, r = oracle.line_coeff([0, 0], [2, 0], normalize=False)
+    assert (p, q, r) == (0.0, 2.0, 0.0)
+
+
+def test_make_gaussian(oracle):
+    w = oracle.make_gaussian(200, 10, 10)
+    i = np.arange(1, 201)
+    assert np.allclose(w, np.exp(-0.5 * ((i - 10) / 10.0) ** 2) / (np.sqrt(2 * np.pi) * 10), rtol=1e-14)
+
+
+def test_compute_steps_structure(oracle):
+    # MPCPlanner.cpp:1188-1329 at the coupled driver's defaults
+    st = oracle.compute_steps(200, 20, [0.15, 0.0], [0.1, 0.2, -0.4, -0.3], [1, -1, 1, -1], oracle.LF)
+    assert st["m"] == 700
+    assert list(np.nonzero(st["swing"][0])[0][:5]) == [5, 6, 7, 8, 9]      # LF swings first
+    assert list(np.nonzero(st["swing"][3])[0][:5]) == [15, 16, 17, 18, 19]  # then RH
+    assert st["hold_x"][0, 0] == pytest.approx(0.25) and st["hold_y"][0, 0] == 1.0
+    A = st["A"]
+    assert ((A != 0).sum(axis=1) <= 2).all()
+    # rows are knot-major, edge-minor: 4 rows per 4-stance knot, 3 per 3-stance knot
+    first_col = np.array([np.nonzero(r)[0][0] % 200 for r in A])
+    assert (np.diff(first_col) >= 0).all()
+    counts = np.bincount(first_col, minlength=200)
+    assert (counts[:5] == 4).all() and (counts[5:10] == 3).all()
+    # a point well inside the support polygon satisfies every row of its knot
+    cx, cy = oracle.centroid(st["fx"], st["fy"], st["swing"])
+    z = np.concatenate([cx, cy])
+    assert (A @ z + st["b"] > 0).all()
+
+
+def test_compute_steps_com_correction(oracle):
+    # :1231-1238, :1266-1283: the first step of each leg is the one-shot correction
+    feet_x, feet_y = [0.1, 0.2, -0.4, -0.3], [1, -1, 1, -1]
+    st = oracle.compute_steps(200, 20, [0.15, 0.02], feet_x, feet_y, oracle.RF, com0=[0.05, 0.01])
+    # RF is third in LF,RH,RF,LH: schedule starts there
+    assert st["swing"][1][5] == 1.0
+    assert st["hold_x"][1, 0] == pytest.approx(0.05 + 0.15)
+    assert st["hold_y"][1, 0] == pytest.approx(0.01 + 0.02)
+    # second time RF swings (4 steps later) it advances by the plain speed
+    assert st["hold_x"][1, 4] == pytest.approx(0.05 + 0.15 + 0.15)
+
+
+def test_default_coupled_scenario(oracle):
+    """Values recorded from the reference's own coupled driver at its defaults
+    (tests/constrainedQP_coupled/testPlannerXYconstraintCoupled.cpp:30-105)."""
+    with open(os.path.join(GOLD, "reference_recorded.json")) as f:
+        gold = json.load(f)["coupled_default"]
+    N, steps = 200, 20
+    p = oracle.params(N, R=0.01, Q=1.0, Qs=100.0, height=0.5)
+    st = oracle.compute_steps(N, steps, [0.15, 0.0], [0.1, 0.2, -0.4, -0.3], [1, -1, 1, -1], oracle.LF)
+    cx, cy = oracle.centroid(st["fx"], st["fy"], st["swing"])
+    r = oracle.solve_coupled(p, oracle.COUPLED_REF, [0, 0, 0], [0, 0, 0], st["A"], st["b"], [0.15, 0.0],
+                             1000, cx, cy)
+    assert np.allclose(r["jerk_x"][:3], gold["jerk_x_0_2"], rtol=2e-6)
+    com = oracle.trajectory(p, 0, [0, 0, 0], r["jerk_x"])
+    assert com[199] == pytest.approx(gold["com_x_199"], rel=2e-6)
+    viol = oracle.constraint_violation(st["swing"], r["viol_all"])
+    assert viol.min() == pytest.approx(gold["min_margin"], rel=2e-5)
+    assert r["info"].n_active == gold["n_active"]
+
+
+def test_default_decoupled_scenario(oracle):
+    """Recorded values of the decoupled driver at its defaults
+    (tests/constrainedQP_decoupled/testPlannerXYconstraintDecoupled.cpp:24-129)."""
+    from mpc_amd import batches
+    with open(os.path.join(GOLD, "reference_recorded.json")) as f:
+        gold = json.load(f)["decoupled_default"]
+    N = 100
+    xmin, xmax, ymin, ymax = (a[0] for a in batches.box_limits(N, 10, 3.0, 0.2))
+    p = oracle.params(N, R=1.0, Q=1.0, height=0.5)
+    jx, ix, ax = oracle.solve_box(p, [0, 0, 0], xmin, xmax)
+    jy, iy, ay = oracle.solve_box(p, [0, 0, 0], ymin, ymax)
+    assert np.allclose(jy[:3], gold["jerk_y_0_2"], rtol=2e-6)
+    assert [(ay >= N).sum(), (ay < N).sum()] == gold["y_active_upper_lower"]
+    assert [(ax >= N).sum(), (ax < N).sum()] == gold["x_active_upper_lower"]
+    zx = oracle.trajectory(p, 3, [0, 0, 0], jx)
+    zy = oracle.trajectory(p, 3, [0, 0, 0], jy)
+    assert (zx >= xmin - 1e-9).all() and (zx <= xmax + 1e-9).all()
+    assert (zy >= ymin - 1e-9).all() and (zy <= ymax + 1e-9).all()
+
+
+def test_dense_and_zero_skipping_modes_agree(oracle):
+    N, steps = 40, 4
+    st = oracle.compute_steps(N, steps, [0.1, 0.02], [0.1, 0.2, -0.4, -0.3], [0.3, -0.3, 0.3, -0.3], oracle.RH)
+    cx, cy = oracle.centroid(st["fx"], st["fy"], st["swing"])
+    for variant in (oracle.COUPLED_JERK, oracle.COUPLED_VEL, oracle.COUPLED_REF):
+        outs = []
+        for dense in (0, 1):
+            p = oracle.params(N, R=0.01, Q=1.0, Qs=100.0, dense=dense)
+            outs.append(oracle.solve_coupled(p, variant, [0.02, 0.1, 0], [0.01, -0.05, 0], st["A"], st["b"],
+                                             [0.1, 0.02], 10, cx, cy))
+        assert np.array_equal(outs[0]["jerk_x"], outs[1]["jerk_x"])
+        assert np.array_equal(outs[0]["jerk_y"], outs[1]["jerk_y"])
+        assert list(outs[0]["active"]) == list(outs[1]["active"])
+
+
+def _kkt(G, g0, CI, ci0, x, active):
+    """Stationarity with non-negative multipliers on the reported working set."""
+    s = CI.T @ x + ci0
+    if len(active):
+        Na = CI[:, active]
+        u, *_ = np.linalg.lstsq(Na, G @ x + g0, rcond=None)
+        resid = G @ x + g0 - Na @ u
+    else:
+        u = np.zeros(0)
+        resid = G @ x + g0
+    return s, u, resid
+
+
+def test_quadprog_kkt_and_scipy(oracle):
+    from scipy.optimize import minimize
+    rng = np.random.default_rng(7)
+    for trial in range(5):
+        n, m = 8, 14
+        M = rng.normal(size=(n, n))
+        G = M @ M.T + 0.5 * np.eye(n)
+        g0 = rng.normal(size=n)
+        CI = rng.normal(size=(n, m))
+        ci0 = rng.uniform(0.1, 1.0, size=m)  # x = 0 strictly feasible
+        x, info, act = oracle.solve_quadprog(G, g0, CI, ci0)
+        assert info.status == oracle.OK
+        s, u, resid = _kkt(G, g0, CI, ci0, x, act)
+        assert s.min() > -1e-9 and np.abs(resid).max() < 1e-9 and (u > -1e-9).all()
+        assert np.abs(s[act]).max(initial=0) < 1e-9
+        assert info.f == pytest.approx(0.5 * x @ G @ x + g0 @ x, rel=1e-10)
+        res = minimize(lambda v: 0.5 * v @ G @ v + g0 @ v, np.zeros(n), jac=lambda v: G @ v + g0,
+                       constraints=[{"type": "ineq", "fun": lambda v: CI.T @ v + ci0,
+                                     "jac": lambda v: CI.T}], method="SLSQP",
+                       options={"ftol": 1e-14, "maxiter": 500})
+        assert np.abs(res.x - x).max() < 1e-5
+
+
+def test_infeasible_and_empty(oracle):
+    G = np.eye(2)
+    # x >= 1 and x <= 0 on the same coordinate
+    CI = np.array([[1.0, -1.0], [0.0, 0.0]])
+    x, info, act = oracle.solve_quadprog(G, np.zeros(2), CI, np.array([-1.0, 0.0]) * 1.0 - np.array([0, 0.5]))
+    assert info.status == oracle.INFEASIBLE and np.isinf(info.f)
+    # no constraints at all: the unconstrained minimiser
+    x, info, act = oracle.solve_quadprog(G * 2, np.array([2.0, -4.0]), np.zeros((2, 0)), np.zeros(0))
+    assert np.allclose(x, [-1.0, 2.0]) and info.n_active == 0 and info.iters == 1
+
+
+def test_unconstrained_solve_qp(oracle):
+    # tests/unconstrainedQP/testPlanner.cpp:21-28,60-64
+    N = 100
+    p = oracle.params(N, R=1e-6, Q=1.0, height=0.5)
+    zref = np.linspace(0, 0.2, N)
+    jerk = oracle.solve_qp(p, [0.2, -0.1, 0.0], zref)
+    zx, zu = oracle.build_matrix(p, 3)
+    G = zu.T @ zu + 1e-6 * np.eye(N)
+    b = zu.T @ (zx @ np.array([0.2, -0.1, 0.0]) - zref)
+    # explicit inverse of an ill-conditioned G (as the reference does): residual relative to |b|
+    assert np.abs(G @ jerk + b).max() < 1e-8 * np.abs(b).max()
+    zmp = oracle.trajectory(p, 3, [0.2, -0.1, 0.0], jerk)
+    assert np.abs(zmp[10:] - zref[10:]).max() < 1e-2
