@@ -21,6 +21,11 @@ _M2 = np.uint64(0x94D049BB133111EB)
 # crawl order of the planner's internal schedule (MPCPlanner.cpp:1197), as LegIDs
 LF, RF, LH, RH = 0, 1, 2, 3
 CRAWL_SEQUENCE = (LF, RH, RF, LH)
+# Hip offsets [leg][x, y] used when the CoM step correction of computeSteps is on
+# (MPCPlanner.cpp:1231-1238).  The reference's replanning driver never sets them (it reads
+# uninitialised memory); zeros would send all four feet to the same point, so the synthetic
+# sweeps use the nominal stance of the coupled driver relative to the CoM.
+NOMINAL_HIP_OFFSETS = np.array([[0.1, 1.0], [0.2, -1.0], [-0.4, 1.0], [-0.3, -1.0]])
 
 
 class SplitMix:

@@ -1208,7 +1208,8 @@ int orc_solve_quadprog(int n, int m, const double *G, const double *g0, const do
 
 int orc_coupled_batch(const orc_params *p, int variant, int steps, int rw, int B, const double *x0,
                       const double *y0, const double *speed, const double *feet_x,
-                      const double *feet_y, const int *swing0, const double *com0, double *jerk_x,
+                      const double *feet_y, const int *swing0, const double *com0,
+                      const double *hip, double *jerk_x,
                       double *jerk_y, double *com_x, double *com_y, double *zmp_x, double *zmp_y,
                       double *viol_knot, double *cost, int *status, int *n_active, int *active,
                       int active_stride, int *iters, double *falg, int nthreads) {
@@ -1226,7 +1227,7 @@ int orc_coupled_batch(const orc_params *p, int variant, int steps, int rw, int B
             int m = pl.computeSteps(speed + 2 * (size_t)i, feet_x + 4 * (size_t)i,
                                     feet_y + 4 * (size_t)i, steps, N, fs, holds, Ap, bv,
                                     swing0 ? swing0[i] : ORC_LF,
-                                    com0 ? com0 + 2 * (size_t)i : zero2, zero8);
+                                    com0 ? com0 + 2 * (size_t)i : zero2, hip ? hip : zero8);
             if (m < 0) {
                 err[tid] = m;
                 return;

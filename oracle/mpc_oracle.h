@@ -133,7 +133,8 @@ int orc_coupled_batch(const orc_params *p, int variant, int steps, int rw,
                       int B, const double *x0, const double *y0,
                       const double *speed, const double *feet_x,
                       const double *feet_y, const int *swing0,
-                      const double *com0, double *jerk_x, double *jerk_y,
+                      const double *com0, const double *hip /* 8 or NULL */,
+                      double *jerk_x, double *jerk_y,
                       double *com_x, double *com_y, double *zmp_x,
                       double *zmp_y, double *viol_knot, double *cost,
                       int *status, int *n_active, int *active, int active_stride,

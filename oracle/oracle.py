@@ -195,11 +195,12 @@ def solve_quadprog(G, g0, CI, ci0, iter_cap=0):
 
 
 def coupled_batch(p, variant, steps, rw, x0, y0, speed, feet_x, feet_y, swing0, com0=None,
-                  active_stride=64, nthreads=1, trajectories=True):
+                  active_stride=64, nthreads=1, trajectories=True, hip=None):
     """The reference planner looped over a batch (one planner per thread)."""
     x0, y0, speed, feet_x, feet_y = _d(x0), _d(y0), _d(speed), _d(feet_x), _d(feet_y)
     swing0 = np.ascontiguousarray(swing0, dtype=np.int32)
     com0_a = _d(com0) if com0 is not None else None
+    hip_a = _d(hip).reshape(8) if hip is not None else None
     B, N = x0.shape[0], p.N
     out = dict(jerk_x=np.zeros((B, N)), jerk_y=np.zeros((B, N)),
                viol_knot=np.zeros((B, N)), cost=np.zeros(B),
@@ -210,7 +211,7 @@ def coupled_batch(p, variant, steps, rw, x0, y0, speed, feet_x, feet_y, swing0, 
         out[k] = np.zeros((B, N)) if trajectories else None
     rc = lib().orc_coupled_batch(
         C.byref(p), variant, steps, int(rw), B, _p(x0), _p(y0), _p(speed), _p(feet_x), _p(feet_y),
-        _p(swing0), _p(com0_a), _p(out["jerk_x"]), _p(out["jerk_y"]), _p(out["com_x"]),
+        _p(swing0), _p(com0_a), _p(hip_a), _p(out["jerk_x"]), _p(out["jerk_y"]), _p(out["com_x"]),
         _p(out["com_y"]), _p(out["zmp_x"]), _p(out["zmp_y"]), _p(out["viol_knot"]),
         _p(out["cost"]), _p(out["status"]), _p(out["n_active"]), _p(out["active"]),
         active_stride, _p(out["iters"]), _p(out["falg"]), nthreads)
