@@ -39,6 +39,8 @@ enum {
     MPCB_UNCONSTRAINED = 4 /* MPCPlanner::solveQP                         (MPCPlanner.cpp:223-237) */
 };
 
+enum { MPCB_MODE_AUTO = 0, MPCB_MODE_DENSE = 1 };
+
 /* Per-instance status written to mpcb_outputs.status. */
 enum {
     MPCB_OK         = 0,
@@ -75,6 +77,9 @@ typedef struct {
     int32_t iter_cap;           /* cap on outer iterations and on step-direction passes;
                                    0 = default (50*(n+m))                          */
     int32_t device;             /* HIP device ordinal                              */
+    int32_t solver_mode;        /* MPCB_MODE_AUTO: structure-exploiting kernel first, dense
+                                   kernel for what it hands over; MPCB_MODE_DENSE: every
+                                   instance through the dense kernel (slow; cross-check)   */
 } mpcb_params;
 
 typedef struct mpcb_handle_s *mpcb_handle;

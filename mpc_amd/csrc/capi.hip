@@ -39,6 +39,9 @@ struct mpcb_handle_s {
     mpcb_params params;
     mpcb::HostSetup hs;
     mpcb::DevSetup ds;
+    mpcb::DenseWs ws;
+    int list_capacity = 0;   // entries ws.list can hold
+    int dense_blocks = 0;    // slots of ws.J / ws.R
     std::vector<void *> dev_allocs;
 };
 
@@ -177,9 +180,73 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
         mpcb_destroy(h);
         return rc;
     }
+    std::memset(&h->ws, 0, sizeof(h->ws));
+    if ((rc = upload_to(h, hs.J0, &h->ws.J1)) || (rc = upload_to(h, hs.zu_col, &h->ws.zu_col)) ||
+        (rc = upload_to(h, hs.xp_col, &h->ws.xp_col)) || (rc = upload_to(h, hs.xv_col, &h->ws.xv_col)) ||
+        (rc = upload_to(h, hs.zx, &h->ws.zx)) || (rc = upload_to(h, hs.xpx, &h->ws.xpx)) ||
+        (rc = upload_to(h, hs.xvx, &h->ws.xvx)) || (rc = upload_to(h, hs.row_knot, &h->ws.row_knot)) ||
+        (rc = upload_to(h, hs.row_slot, &h->ws.row_slot))) {
+        mpcb_destroy(h);
+        return rc;
+    }
+    {
+        int *cnt = nullptr;
+        if (hipMalloc((void **)&cnt, sizeof(int)) != hipSuccess) {
+            mpcb_destroy(h);
+            return fail(MPCB_E_HIP, "hipMalloc failed");
+        }
+        h->dev_allocs.push_back(cnt);
+        h->ws.count = cnt;
+    }
     *out = h;
     return 0;
 }
+
+namespace {
+
+// Grows the hand-over list and the dense kernel's HBM workspace to fit a batch of B.
+int ensure_workspace(mpcb_handle h, int B) {
+    if (B > h->list_capacity) {
+        int *lst = nullptr;
+        HIP_TRY(hipMalloc((void **)&lst, (size_t)B * sizeof(int)));
+        h->dev_allocs.push_back(lst);
+        h->ws.list = lst;
+        h->list_capacity = B;
+    }
+    // one J and one R slot per resident workgroup; more flagged instances than slots
+    // are handled by the kernel's loop over the list
+    const int want = B < 512 ? B : 512;
+    if (want > h->dense_blocks) {
+        const size_t n = (size_t)h->hs.N * h->hs.axes;
+        double *J = nullptr, *R = nullptr;
+        HIP_TRY(hipMalloc((void **)&J, (size_t)want * n * n * sizeof(double)));
+        h->dev_allocs.push_back(J);
+        HIP_TRY(hipMalloc((void **)&R, (size_t)want * n * n * sizeof(double)));
+        h->dev_allocs.push_back(R);
+        h->ws.J = J;
+        h->ws.R = R;
+        h->dense_blocks = want;
+    }
+    return 0;
+}
+
+// first stage (wave per QP), then the dense kernel over whatever it handed over
+int solve_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &out, int B, hipStream_t stream) {
+    if (B == 0) return 0;
+    int rc = ensure_workspace(h, B);
+    if (rc) return rc;
+    if (h->params.solver_mode == MPCB_MODE_DENSE) {
+        HIP_TRY(mpcb::launch_list_all(h->ws, B, stream));
+    } else {
+        HIP_TRY(hipMemsetAsync(h->ws.count, 0, sizeof(int), stream));
+        HIP_TRY(mpcb::launch_zspace(h->ds, di, out, B, h->ws, stream));
+    }
+    const int blocks = B < h->dense_blocks ? B : h->dense_blocks;
+    HIP_TRY(mpcb::launch_dense(h->ds, di, out, h->ws, blocks, stream));
+    return 0;
+}
+
+} // namespace
 
 void mpcb_destroy(mpcb_handle h) {
     if (!h) return;
@@ -229,8 +296,7 @@ int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_input
     di.feet_y = in->feet_y;
     di.swing0 = in->swing0;
     di.com0 = in->com0;
-    HIP_TRY(mpcb::launch_zspace(h->ds, di, *out, B, (hipStream_t)stream));
-    return 0;
+    return solve_two_stage(h, di, *out, B, (hipStream_t)stream);
 }
 
 int mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const double *zmin,
@@ -246,8 +312,7 @@ int mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const doub
     di.x0 = x0;
     di.zmin = zmin;
     di.zmax = zmax;
-    HIP_TRY(mpcb::launch_zspace(h->ds, di, *out, B, (hipStream_t)stream));
-    return 0;
+    return solve_two_stage(h, di, *out, B, (hipStream_t)stream);
 }
 
 int mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, const mpcb_outputs *out) {

@@ -1,0 +1,185 @@
+// Device helpers shared by the wave-per-QP kernel and the dense fallback kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace mpcb {
+
+constexpr double EPS = 2.220446049250313e-16;
+constexpr double DINF = __builtin_huge_val();
+
+// LDS traffic between lanes of one wave: the hardware executes a wave's LDS
+// instructions in order, so only the compiler has to be kept from reordering.
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int ufirst(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ double ufirst(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return ufirst(v);
+}
+
+// Minimum of (val, key); the smaller key wins ties.  Result is wave-uniform.
+__device__ __forceinline__ void wave_argmin(double &val, int &key, int &aux) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(val, o, 64);
+        const int ok = __shfl_xor(key, o, 64);
+        const int oa = __shfl_xor(aux, o, 64);
+        if (ov < val || (ov == val && ok < key)) {
+            val = ov;
+            key = ok;
+            aux = oa;
+        }
+    }
+    val = ufirst(val);
+    key = ufirst(key);
+    aux = ufirst(aux);
+}
+
+// eiquadprog.hpp:90-108
+__device__ __forceinline__ double distance(double a, double b) {
+    const double a1 = fabs(a), b1 = fabs(b);
+    if (a1 > b1) {
+        const double t = b1 / a1;
+        return a1 * sqrt(1.0 + t * t);
+    } else if (b1 > a1) {
+        const double t = a1 / b1;
+        return b1 * sqrt(1.0 + t * t);
+    }
+    return a1 * sqrt(2.0);
+}
+
+
+// computeSteps (MPCPlanner.cpp:1188-1329) + buildPolygonMatrix (:1040-1082) for ONE
+// phase of one instance.  The calling thread replays the footstep schedule (cheap:
+// number_of_steps additions per foot), keeps the feet as they stand during phase
+// `myph` (even = four feet down, odd = the scheduled leg in swing, 2*steps = the
+// trailing four-stance knots) and writes that phase's edges (p, q, r) to
+// tab[(myph*4 + edge)*3 ..].  speed = userSpeed, used as per-step displacement.
+__device__ inline void polygon_phase(const DevSetup &sd, const DevIn &in, int inst, double spx,
+                                     double spy, int myph, double *tab) {
+    const double *pfx = in.feet_x + (size_t)inst * 4, *pfy = in.feet_y + (size_t)inst * 4;
+    double c0x = 0.0, c0y = 0.0;
+    if (in.com0) {
+        c0x = in.com0[(size_t)inst * 2];
+        c0y = in.com0[(size_t)inst * 2 + 1];
+    }
+    const bool correct = !(c0x == 0.0 && c0y == 0.0); // initialCoM.isZero(0), :1231
+    const int swing0 = in.swing0[inst];
+    // schedule LF, RH, RF, LH (:1197); setCurrentSwing (FootScheduler.h:33-43)
+    int cur = 0;
+    if (swing0 == 3) cur = 1;
+    else if (swing0 == 1) cur = 2;
+    else if (swing0 == 2) cur = 3;
+    double fx[4], fy[4], sx[4], sy[4], corrx[4], corry[4];
+    bool flag[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        fx[l] = pfx[l];
+        fy[l] = pfy[l];
+        sx[l] = fx[l];
+        sy[l] = fy[l];
+        flag[l] = correct;
+        corrx[l] = ((c0x + sd.hip[2 * l]) + spx) - fx[l]; // :1234-1237
+        corry[l] = ((c0y + sd.hip[2 * l + 1]) + spy) - fy[l];
+    }
+    int excl = -1;
+    for (int i = 0; i < sd.steps; i++) {
+        if (myph == 2 * i) {
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                sx[l] = fx[l];
+                sy[l] = fy[l];
+            }
+            excl = -1;
+        }
+        const int sw = (cur == 0) ? 0 : (cur == 1) ? 3 : (cur == 2) ? 1 : 2;
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            if (l == sw) {
+                const double dx = flag[l] ? corrx[l] : spx; // :1266-1280
+                const double dy = flag[l] ? corry[l] : spy;
+                flag[l] = false;
+                fx[l] += dx;
+                fy[l] += dy;
+            }
+        }
+        if (myph == 2 * i + 1) {
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                sx[l] = fx[l];
+                sy[l] = fy[l];
+            }
+            excl = sw;
+        }
+        cur = (cur + 1) & 3;
+    }
+    if (myph == 2 * sd.steps) {
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            sx[l] = fx[l];
+            sy[l] = fy[l];
+        }
+        excl = -1;
+    }
+    if (myph >= sd.nphase) return;
+    const int E = excl < 0 ? 4 : 3;
+    double px[4], py[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { // stance feet in LegID order (:1052-1059)
+        const int leg = e + ((excl >= 0 && e >= excl) ? 1 : 0);
+        px[e] = leg == 0 ? sx[0] : leg == 1 ? sx[1] : leg == 2 ? sx[2] : sx[3];
+        py[e] = leg == 0 ? sy[0] : leg == 1 ? sy[1] : leg == 2 ? sy[2] : sy[3];
+    }
+    // CounterClockwiseSort (planning.h:182-197), pivot p[0]
+    auto right_of = [&](int a, int b) { // Point2isRightOfLine(p0, pa, pb), :143-149
+        return (px[b] - px[0]) * (py[a] - py[0]) - (px[a] - px[0]) * (py[b] - py[0]);
+    };
+    auto swp = [&](int a, int b) {
+        double t = px[a];
+        px[a] = px[b];
+        px[b] = t;
+        t = py[a];
+        py[a] = py[b];
+        py[b] = t;
+    };
+    if (right_of(1, 2) > 0.0) swp(1, 2);
+    if (E == 4) {
+        if (right_of(1, 3) > 0.0) swp(1, 3);
+        if (right_of(2, 3) > 0.0) swp(2, 3);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if (e < E) {
+            // LineCoeff(pt_e, pt_{(e+1)%E}, normalize) (planning.h:236-260)
+            const int nx = (e + 1 == E) ? 0 : e + 1;
+            const double bx = nx == 0 ? px[0] : nx == 1 ? px[1] : nx == 2 ? px[2] : px[3];
+            const double by = nx == 0 ? py[0] : nx == 1 ? py[1] : nx == 2 ? py[2] : py[3];
+            double p = py[e] - by, q = bx - px[e];
+            double r = -p * px[e] - q * py[e];
+            const double norm = hypot(p, q);
+            p /= norm;
+            q /= norm;
+            r /= norm;
+            double *t = tab + (myph * 4 + e) * 3;
+            t[0] = p;
+            t[1] = q;
+            t[2] = r;
+        }
+    }
+}
+
+} // namespace mpcb

@@ -260,6 +260,10 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
 
     o.zu_col = to_double(Z.col);
     o.zx = to_double(Z.sx);
+    o.xp_col = to_double(Xp.col);
+    o.xpx = to_double(Xp.sx);
+    o.xv_col = to_double(Xv.col);
+    o.xvx = to_double(Xv.sx);
     {
         // J0 = L^-T: solve L^T J0 = I column by column (upper triangular result)
         LVec J0((size_t)N * N, 0);

@@ -29,6 +29,7 @@ struct HostSetup {
     std::vector<int> row_knot, row_slot;      // [m]
     // kept for the dense fallback and the unconstrained solve
     std::vector<double> zu_col, zx;           // Toeplitz first column of Zu; Zx (N x 3)
+    std::vector<double> xp_col, xpx, xv_col, xvx; // the same for CoM position and velocity
     std::vector<double> J0;                   // L1^-T (N x N, column-major), upper triangular
     std::vector<double> Hneg;                 // -G1^-1 (N x N) row-major
 };

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmpc_amd.so")
 
 BOX_1D, COUPLED_JERK, COUPLED_VEL, COUPLED_REF, UNCONSTRAINED = 0, 1, 2, 3, 4
 OK, INFEASIBLE, ITER_CAP = 0, 1, 2
+MODE_AUTO, MODE_DENSE = 0, 1
 
 # every symbol include/mpc_amd.h declares
 EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constraints",
@@ -28,7 +29,8 @@ class Params(C.Structure):
                 ("gravity", C.c_double), ("height", C.c_double), ("weight_R", C.c_double),
                 ("weight_Q", C.c_double), ("weight_Qs", C.c_double),
                 ("replanning_window", C.c_int32), ("number_of_steps", C.c_int32),
-                ("hip_offsets", C.c_double * 8), ("iter_cap", C.c_int32), ("device", C.c_int32)]
+                ("hip_offsets", C.c_double * 8), ("iter_cap", C.c_int32), ("device", C.c_int32),
+                ("solver_mode", C.c_int32)]
 
 
 class CoupledInputs(C.Structure):
@@ -95,7 +97,8 @@ class BatchedPlanner:
 
     def __init__(self, horizon, Ts=0.1, gravity=9.81, formulation=COUPLED_VEL, height=0.5,
                  weight_R=1e-6, weight_Q=1.0, weight_Qs=100.0, replanning_window=1000,
-                 number_of_steps=20, hip_offsets=None, iter_cap=0, device=0, active_stride=64):
+                 number_of_steps=20, hip_offsets=None, iter_cap=0, device=0, active_stride=64,
+                 solver_mode=0):
         import torch
         self._torch = torch
         lib = load_library()
@@ -108,6 +111,7 @@ class BatchedPlanner:
         for i in range(8):
             p.hip_offsets[i] = float(hip[i])
         p.iter_cap, p.device = int(iter_cap), int(device)
+        p.solver_mode = int(solver_mode)
         self.params = p
         self.horizon = int(horizon)
         self.formulation = int(formulation)
