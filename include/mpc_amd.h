@@ -134,6 +134,32 @@ int  mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_inpu
 int  mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in,
                         const mpcb_outputs *out);
 
+/* State of B receding-horizon rollouts between two replans (device pointers, updated in
+ * place): what the loop of tests/replanning/testPlannerXYconstraintMPC.cpp keeps in
+ * actual_state_x/y, initial_feet_x/y and replanning_schedule. */
+typedef struct {
+    double        *x0, *y0;       /* [B][3] actual CoM state                                  */
+    const double  *speed;         /* [B][2] userSpeed                                         */
+    double        *feet_x, *feet_y; /* [B][4]                                                 */
+    int32_t       *swing0;        /* [B]    leg the next plan starts swinging                 */
+    double        *com0;          /* [B][2] scratch: CoM handed to computeSteps               */
+    const double  *disturbance;   /* [B]    added to the Y jerk from sample disturbance_start
+                                            on (testPlannerXYconstraintMPC.cpp:104,207); NULL = none */
+} mpcb_replan_state;
+
+/* n_stages sequentially dependent replans of B rollouts without leaving the device
+ * (testPlannerXYconstraintMPC.cpp:108-209 with optimizeVelocity on): per stage
+ * computeSteps from the actual CoM (step correction if use_com_correction) ->
+ * solveQPConstraintCoupled -> computeCOMupdate over floor(N/number_of_steps) samples ->
+ * feet taken from the plan, schedule advanced.  `out` receives the LAST stage's plan and
+ * must provide jerk_x, jerk_y, cost and status; stage_cost / stage_status / stage_nactive
+ * ([n_stages][B], any may be NULL) record every stage.  The handle must be COUPLED_VEL or
+ * COUPLED_JERK.  Infeasible stages contribute zero jerk. */
+int  mpcb_replan_sweep_device(mpcb_handle h, int32_t B, int32_t n_stages, int32_t use_com_correction,
+                              int32_t disturbance_start, const mpcb_replan_state *state,
+                              const mpcb_outputs *out, double *stage_cost, int32_t *stage_status,
+                              int32_t *stage_nactive, void *stream);
+
 /* 1-D box-constrained plan: solveQPconstraint for B instances (one axis each).
  * x0 [B][3], zmin/zmax [B][N] (BoxLimits, MPCPlanner.h:29-34).  Outputs: the *_x
  * members; active_idx < N is the lower bound of that knot, >= N the upper bound. */

@@ -175,6 +175,9 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
         (rc = upload_to(h, hs.Sc, &ds.Sc)) || (rc = upload_to(h, hs.Sv, &ds.Sv)) ||
         (rc = upload_to(h, hs.Kx, &ds.Kx)) || (rc = upload_to(h, hs.Kz, &ds.Kz)) ||
         (rc = upload_to(h, hs.Kc, &ds.Kc)) || (rc = upload_to(h, hs.Kv, &ds.Kv)) ||
+        (rc = upload_to(h, hs.Sp, &ds.Sp)) || (rc = upload_to(h, hs.Wp, &ds.Wp)) ||
+        (rc = upload_to(h, hs.Scp, &ds.Scp)) || (rc = upload_to(h, hs.Svp, &ds.Svp)) ||
+        (rc = upload_to(h, hs.F2, &ds.F2)) || (rc = upload_to(h, hs.F3, &ds.F3)) ||
         (rc = upload_to(h, hs.knot_phase, &ds.knot_phase)) ||
         (rc = upload_to(h, hs.knot_row0, &ds.knot_row0))) {
         mpcb_destroy(h);
@@ -280,8 +283,8 @@ int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_input
                               const mpcb_outputs *out, void *stream) {
     if (!h || !in || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
     const int form = h->params.formulation;
-    if (form != MPCB_COUPLED_JERK && form != MPCB_COUPLED_VEL)
-        return fail(MPCB_E_ARG, "handle was not created for a coupled formulation supported here");
+    if (form != MPCB_COUPLED_JERK && form != MPCB_COUPLED_VEL && form != MPCB_COUPLED_REF)
+        return fail(MPCB_E_ARG, "handle was not created for a coupled formulation");
     if (!in->x0 || !in->y0 || !in->speed || !in->feet_x || !in->feet_y || !in->swing0)
         return fail(MPCB_E_ARG, "missing coupled input array");
     if ((out->active_idx || out->multipliers) && out->active_stride <= 0)
@@ -297,6 +300,68 @@ int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_input
     di.swing0 = in->swing0;
     di.com0 = in->com0;
     return solve_two_stage(h, di, *out, B, (hipStream_t)stream);
+}
+
+int mpcb_replan_sweep_device(mpcb_handle h, int32_t B, int32_t n_stages, int32_t use_com_correction,
+                             int32_t disturbance_start, const mpcb_replan_state *state,
+                             const mpcb_outputs *out, double *stage_cost, int32_t *stage_status,
+                             int32_t *stage_nactive, void *stream) {
+    if (!h || !state || !out || B < 0 || n_stages < 0) return fail(MPCB_E_ARG, "null argument or negative size");
+    const int form = h->params.formulation;
+    if (form != MPCB_COUPLED_JERK && form != MPCB_COUPLED_VEL)
+        return fail(MPCB_E_ARG, "replanning needs a COUPLED_VEL or COUPLED_JERK handle");
+    if (!state->x0 || !state->y0 || !state->speed || !state->feet_x || !state->feet_y || !state->swing0 ||
+        !state->com0)
+        return fail(MPCB_E_ARG, "missing replanning state array");
+    if (!out->jerk_x || !out->jerk_y || !out->cost || !out->status)
+        return fail(MPCB_E_ARG, "replanning needs the jerk_x, jerk_y, cost and status outputs");
+    const int window = h->hs.N / h->hs.steps; // replanningWindow (testPlannerXYconstraintMPC.cpp:95)
+    if (window < 1) return fail(MPCB_E_ARG, "horizon shorter than number_of_steps");
+    DeviceGuard guard(h->params.device);
+    hipStream_t s = (hipStream_t)stream;
+    mpcb::ReplanState rs;
+    rs.x0 = state->x0;
+    rs.y0 = state->y0;
+    rs.speed = state->speed;
+    rs.feet_x = state->feet_x;
+    rs.feet_y = state->feet_y;
+    rs.swing0 = state->swing0;
+    rs.com0 = state->com0;
+    rs.disturbance = state->disturbance;
+    HIP_TRY(mpcb::launch_replan_init(rs, B, use_com_correction, s));
+    mpcb::DevIn di;
+    std::memset(&di, 0, sizeof(di));
+    di.x0 = rs.x0;
+    di.y0 = rs.y0;
+    di.speed = rs.speed;
+    di.feet_x = rs.feet_x;
+    di.feet_y = rs.feet_y;
+    di.swing0 = rs.swing0;
+    di.com0 = rs.com0;
+    mpcb::ReplanStep sp;
+    std::memset(&sp, 0, sizeof(sp));
+    sp.window = window;
+    sp.N = h->hs.N;
+    sp.disturbance_start = disturbance_start;
+    sp.use_com_correction = use_com_correction;
+    sp.feet_move = h->hs.phase_knots > 0; // with empty phases knot sampleW still shows the old feet
+    sp.Ts = h->params.Ts;
+    std::memcpy(sp.hip, h->params.hip_offsets, sizeof(sp.hip));
+    sp.jerk_x = out->jerk_x;
+    sp.jerk_y = out->jerk_y;
+    sp.cost = out->cost;
+    sp.status = out->status;
+    sp.n_active = out->n_active;
+    sp.stage_cost = stage_cost;
+    sp.stage_status = stage_status;
+    sp.stage_nactive = stage_nactive;
+    for (int stage = 0; stage < n_stages; stage++) {
+        int rc = solve_two_stage(h, di, *out, B, s);
+        if (rc) return rc;
+        sp.stage = stage;
+        HIP_TRY(mpcb::launch_replan_advance(rs, sp, B, s));
+    }
+    return 0;
 }
 
 int mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const double *zmin,

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
     double *zx = s + m, *zy = zx + N;
     double *lo = zy + N, *hi = lo + N;                                   // BOX limits
     double *tab = hi + N;                                                // POLY: [phase][edge][p,q,r]
-    double *red = tab + (POLY ? sd.nphase * 12 : 0);
+    double *cref = tab + (POLY ? sd.nphase * 12 : 0);                    // POLY: [phase][x,y]
+    double *red = cref + (POLY ? sd.nphase * 2 : 0);
     int *redk = reinterpret_cast<int *>(red + 4);
     int *A = redk + 4, *A_old = A + (n + 1), *iai = A_old + (n + 1);
     int *iaexcl = iai + m;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             }
         }
         if constexpr (POLY) {
-            for (int phb = 0; phb < sd.nphase; phb += T) polygon_phase(sd, in, inst, wx[3], wy[3], phb + tid, tab);
+            for (int phb = 0; phb < sd.nphase; phb += T) polygon_phase(sd, in, inst, wx[3], wy[3], phb + tid, tab, cref);
         } else {
             for (int k = tid; k < N; k += T) {
                 lo[k] = in.zmin[(size_t)inst * N + k];
@@ -173,11 +174,22 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             const int k = i < N ? i : i - N;
             const double *kx = sd.Kx + (size_t)k * 4;
             const double *w = i < N ? wx : wy;
-            x[i] = kx[0] * w[0] + kx[1] * w[1] + kx[2] * w[2] + kx[3] * w[3];
+            double v = kx[0] * w[0] + kx[1] * w[1] + kx[2] * w[2] + kx[3] * w[3];
+            if constexpr (POLY) {
+                if (sd.Wp)
+                    for (int p2 = 0; p2 < sd.nphase; p2++)
+                        v += cref[2 * p2 + (i < N ? 0 : 1)] * sd.Wp[(size_t)p2 * N + k];
+            }
+            x[i] = v;
         }
-        double f = 0.0;
-        for (int a = 0; a < 4; a++)
-            for (int b = 0; b < 4; b++) f += sd.F[a * 4 + b] * (wx[a] * wx[b] + wy[a] * wy[b]);
+        double f;
+        {
+            double fp = 0.0;
+            for (int pb = 0; pb < (sd.F2 ? sd.nphase : 1); pb += T)
+                fp += unconstrained_cost_part(sd, wx, cref, 0, pb + tid, pb + tid == 0) +
+                      unconstrained_cost_part(sd, wy, cref, 1, pb + tid, pb + tid == 0);
+            f = block_sum(fp, red, tid);
+        }
         for (int i = tid; i < m; i += T) iai[i] = i;
         double R_norm = 1.0;
         int iq = 0, iters = 0, passes = 0, status = MPCB_OK;
@@ -574,7 +586,7 @@ __global__ void list_all_kernel(int *list, int *count, int B) {
 
 size_t dense_lds_bytes(const DevSetup &sd) {
     const size_t N = sd.N, n = sd.axes * N, m = sd.m;
-    size_t doubles = 5 * n + 3 * (n + 1) + 3 * n + (n + 1) + m + 4 * N + (size_t)sd.nphase * 12 + 4;
+    size_t doubles = 5 * n + 3 * (n + 1) + 3 * n + (n + 1) + m + 4 * N + (size_t)sd.nphase * 14 + 4;
     size_t ints = 4 + 2 * (n + 1) + 2 * m;
     return doubles * 8 + ints * 4 + 64;
 }

@@ -69,8 +69,10 @@ __device__ __forceinline__ double distance(double a, double b) {
 // `myph` (even = four feet down, odd = the scheduled leg in swing, 2*steps = the
 // trailing four-stance knots) and writes that phase's edges (p, q, r) to
 // tab[(myph*4 + edge)*3 ..].  speed = userSpeed, used as per-step displacement.
+// cref (may be NULL) receives the centroid of the phase's stance feet, the ZMP
+// reference of computeCentroid (MPCPlanner.cpp:1106-1130), at cref[2*myph .. +1].
 __device__ inline void polygon_phase(const DevSetup &sd, const DevIn &in, int inst, double spx,
-                                     double spy, int myph, double *tab) {
+                                     double spy, int myph, double *tab, double *cref) {
     const double *pfx = in.feet_x + (size_t)inst * 4, *pfy = in.feet_y + (size_t)inst * 4;
     double c0x = 0.0, c0y = 0.0;
     if (in.com0) {
@@ -137,6 +139,17 @@ __device__ inline void polygon_phase(const DevSetup &sd, const DevIn &in, int in
     }
     if (myph >= sd.nphase) return;
     const int E = excl < 0 ? 4 : 3;
+    if (cref) {
+        double sumx = 0.0, sumy = 0.0;
+#pragma unroll
+        for (int l = 0; l < 4; l++)
+            if (l != excl) {
+                sumx += sx[l];
+                sumy += sy[l];
+            }
+        cref[2 * myph] = sumx / E;
+        cref[2 * myph + 1] = sumy / E;
+    }
     double px[4], py[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) { // stance feet in LegID order (:1052-1059)
@@ -180,6 +193,30 @@ __device__ inline void polygon_phase(const DevSetup &sd, const DevIn &in, int in
             t[2] = r;
         }
     }
+}
+
+// Cost of the unconstrained minimiser, f = 1/2 g0'x (eiquadprog.hpp:191), for one axis:
+// w'Fw, plus for the ZMP-reference formulation the terms in the per-phase reference c.
+// Call with every index ph in [0, nphase) covered once over the calling threads and
+// sum the results; `base` adds w'Fw (pass true from exactly one thread).
+__device__ __forceinline__ double unconstrained_cost_part(const DevSetup &sd, const double w[4],
+                                                          const double *cref, int axis, int ph,
+                                                          bool base) {
+    double f = 0.0;
+    if (base) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) f += sd.F[a * 4 + b] * w[a] * w[b];
+    }
+    if (sd.F2 && ph < sd.nphase) {
+        double t = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; a++) t += w[a] * sd.F2[a * sd.nphase + ph];
+        for (int p2 = 0; p2 < sd.nphase; p2++) t += sd.F3[ph * sd.nphase + p2] * cref[2 * p2 + axis];
+        f += t * cref[2 * ph + axis];
+    }
+    return f;
 }
 
 } // namespace mpcb

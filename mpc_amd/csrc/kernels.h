@@ -18,6 +18,10 @@ struct DevSetup {
     int iter_cap;
     const double *S, *Wt, *Sc, *Sv;   // N x N response matrices, row k = knot k
     const double *Kx, *Kz, *Kc, *Kv;  // N x 4 unconstrained responses
+    // ZMP-reference formulation only (else NULL): responses to a unit reference on the
+    // knots of one phase, [nphase][N], weight Qs folded in; cost terms F2 [4][nphase],
+    // F3 [nphase][nphase]
+    const double *Sp, *Wp, *Scp, *Svp, *F2, *F3;
     const int *knot_phase, *knot_row0; // [N]
     double F[16];
     double psi_thr;                   // m * eps * c1 * c2 * 100 (eiquadprog.hpp:267)
@@ -55,5 +59,29 @@ hipError_t launch_list_all(const DenseWs &ws, int B, hipStream_t stream);
 // ws.J / ws.R and loops over list entries blockIdx.x, blockIdx.x + blocks, ...).
 hipError_t launch_dense(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, const DenseWs &ws,
                         int blocks, hipStream_t stream);
+
+// Receding-horizon sweep: mutable per-rollout state and the per-stage arguments of the
+// advance kernel.
+struct ReplanState {
+    double *x0, *y0;            // [B][3]
+    const double *speed;        // [B][2]
+    double *feet_x, *feet_y;    // [B][4]
+    int *swing0;                // [B]
+    double *com0;               // [B][2]
+    const double *disturbance;  // [B] or NULL
+};
+
+struct ReplanStep {
+    int stage, window, N, disturbance_start, use_com_correction, feet_move;
+    double Ts;
+    double hip[8];
+    const double *jerk_x, *jerk_y, *cost;
+    const int *status, *n_active;
+    double *stage_cost;
+    int *stage_status, *stage_nactive;
+};
+
+hipError_t launch_replan_init(const ReplanState &st, int B, int use_com_correction, hipStream_t stream);
+hipError_t launch_replan_advance(const ReplanState &st, const ReplanStep &sp, int B, hipStream_t stream);
 
 } // namespace mpcb

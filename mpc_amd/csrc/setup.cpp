@@ -323,6 +323,36 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
                 o.row_slot[o.knot_row0[k] + e] = e;
             }
         }
+        if (form == MPCB_COUPLED_REF) {
+            // The reference of computeCentroid is constant over a phase, so its effect is
+            // a sum over phases of (centroid of the phase) x (response summed over the
+            // phase's knots).  g0 gains -Qs Zu' zref (MPCPlanner.cpp:731-735).
+            const int P = o.nphase;
+            const ld Qs = p.weight_Qs;
+            LVec Sp((size_t)P * N, 0), Wp((size_t)P * N, 0), Scp((size_t)P * N, 0), Svp((size_t)P * N, 0);
+            LVec F2((size_t)4 * P, 0), F3((size_t)P * P, 0);
+            for (int k = 0; k < N; k++) {
+                const int ph = o.knot_phase[k];
+                for (int i = 0; i < N; i++) {
+                    Sp[(size_t)ph * N + i] += Qs * S[(size_t)k * N + i];
+                    Wp[(size_t)ph * N + i] += Qs * W[(size_t)i * N + k];
+                    Scp[(size_t)ph * N + i] += Qs * Sc[(size_t)i * N + k];
+                    Svp[(size_t)ph * N + i] += Qs * Sv[(size_t)i * N + k];
+                }
+                for (int a = 0; a < 4; a++) {
+                    const ld zukx = Kz[(size_t)k * 4 + a] - (a < 3 ? Z.sx[(size_t)k * 3 + a] : 0);
+                    F2[(size_t)a * P + ph] -= Qs * zukx;
+                }
+                for (int k2 = 0; k2 < N; k2++)
+                    F3[(size_t)ph * P + o.knot_phase[k2]] -= Qs * Qs * S[(size_t)k * N + k2] / 2;
+            }
+            o.Sp = to_double(Sp);
+            o.Wp = to_double(Wp);
+            o.Scp = to_double(Scp);
+            o.Svp = to_double(Svp);
+            o.F2 = to_double(F2);
+            o.F3 = to_double(F3);
+        }
     } else {
         o.m = (form == MPCB_BOX_1D) ? 2 * N : 0;
         o.nphase = 0;

@@ -22,6 +22,8 @@ struct HostSetup {
     // N x 4: unconstrained response to w = (pos, vel, acc, target speed)
     std::vector<double> Kx, Kz, Kc, Kv;
     double F[16];         // f_unc = w^T F w per axis
+    // ZMP-reference formulation: per-phase responses [nphase][N] and cost terms
+    std::vector<double> Sp, Wp, Scp, Svp, F2, F3;
     double c1 = 0, c2 = 0;   // trace(G), trace(L^-T) of the full Hessian (eiquadprog.hpp:162,176)
     double traceG1 = 0;
     // row bookkeeping of computeSteps / buildPolygonMatrix

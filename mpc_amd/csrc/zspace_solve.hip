@@ -133,10 +133,11 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
     const int inst = ufirst((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (inst >= B) return;
     const int N = sd.N;
-    const int tab_doubles = POLY ? sd.nphase * 12 : 0;
+    const int tab_doubles = POLY ? sd.nphase * 14 : 0;
     const int per_wave = (int)(sizeof(WaveState) / 8) + tab_doubles;
     WaveState &W = *reinterpret_cast<WaveState *>(smem + (size_t)wv * per_wave);
     double *tab = smem + (size_t)wv * per_wave + sizeof(WaveState) / 8; // [phase][edge][p,q,r]
+    double *cref = tab + (POLY ? sd.nphase * 12 : 0);                    // [phase][x,y] ZMP reference
 
     // ---- owned knots ------------------------------------------------------
     int kn[NPL], kc[NPL];
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
     if constexpr (POLY) {
         // computeSteps + buildPolygonMatrix: lane l builds the polygon of phase l
         for (int pbase = 0; pbase < sd.nphase; pbase += 64)
-            polygon_phase(sd, in, inst, wx[3], wy[3], pbase + lane, tab);
+            polygon_phase(sd, in, inst, wx[3], wy[3], pbase + lane, tab, cref);
 #pragma unroll
         for (int c = 0; c < NPL; c++) {
             ph[c] = sd.knot_phase[kc[c]];
@@ -225,11 +226,26 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
         zxu[c] = kz[0] * wx[0] + kz[1] * wx[1] + kz[2] * wx[2] + kz[3] * wx[3];
         zyu[c] = kz[0] * wy[0] + kz[1] * wy[1] + kz[2] * wy[2] + kz[3] * wy[3];
     }
-    double f = 0.0;
+    double f;
+    {
+        double fp = 0.0;
+        for (int pb = 0; pb < (sd.F2 ? sd.nphase : 1); pb += 64)
+            fp += unconstrained_cost_part(sd, wx, cref, 0, pb + lane, pb + lane == 0) +
+                  unconstrained_cost_part(sd, wy, cref, 1, pb + lane, pb + lane == 0);
+        f = wave_sum(fp);
+    }
+    if constexpr (POLY) {
+        if (sd.Sp) // ZMP-reference formulation: response to the per-phase reference
+            for (int p2 = 0; p2 < sd.nphase; p2++) {
+                const double cxr = cref[2 * p2], cyr = cref[2 * p2 + 1];
 #pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) f += sd.F[a * 4 + b] * (wx[a] * wx[b] + wy[a] * wy[b]);
+                for (int c = 0; c < NPL; c++) {
+                    const double sv = sd.Sp[(size_t)p2 * N + kc[c]];
+                    zxu[c] += cxr * sv;
+                    zyu[c] += cyr * sv;
+                }
+            }
+    }
 
     // ---- dual active-set loop ----------------------------------------------
     int iq = 0, iters = 0, passes = 0, status = MPCB_OK;
@@ -539,7 +555,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
         nresp = iq + 1;
     }
     wsync();
-    auto respond = [&](const double *K, const double *M, double *ox, double *oy) {
+    auto respond = [&](const double *K, const double *M, const double *Mp, double *ox, double *oy) {
         if (!ox && !oy) return;
         double vx[NPL], vy[NPL];
 #pragma unroll
@@ -547,6 +563,18 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
             const double *k4 = K + (size_t)kc[c] * 4;
             vx[c] = k4[0] * wx[0] + k4[1] * wx[1] + k4[2] * wx[2] + k4[3] * wx[3];
             vy[c] = k4[0] * wy[0] + k4[1] * wy[1] + k4[2] * wy[2] + k4[3] * wy[3];
+        }
+        if constexpr (POLY) {
+            if (Mp)
+                for (int p2 = 0; p2 < sd.nphase; p2++) {
+                    const double cxr = cref[2 * p2], cyr = cref[2 * p2 + 1];
+#pragma unroll
+                    for (int c = 0; c < NPL; c++) {
+                        const double mv = Mp[(size_t)p2 * N + kc[c]];
+                        vx[c] += cxr * mv;
+                        vy[c] += cyr * mv;
+                    }
+                }
         }
         for (int a = 0; a < nresp; a++) {
             const int ka = ufirst(W.wsKS[a]) >> 2;
@@ -566,9 +594,9 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                 if (oy) oy[(size_t)inst * N + kn[c]] = solved ? vy[c] : 0.0;
             }
     };
-    respond(sd.Kx, sd.Wt, out.jerk_x, out.jerk_y);
-    respond(sd.Kc, sd.Sc, out.com_x, out.com_y);
-    respond(sd.Kv, sd.Sv, out.com_xd, out.com_yd);
+    respond(sd.Kx, sd.Wt, sd.Wp, out.jerk_x, out.jerk_y);
+    respond(sd.Kc, sd.Sc, sd.Scp, out.com_x, out.com_y);
+    respond(sd.Kv, sd.Sv, sd.Svp, out.com_xd, out.com_yd);
     if (out.zmp_x || out.zmp_y || out.min_margin) {
         double vx[NPL], vy[NPL];
 #pragma unroll
@@ -608,7 +636,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
 template <int NPL, bool POLY>
 hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
                       const DenseWs &ws, hipStream_t stream) {
-    const size_t per_wave = sizeof(WaveState) + (POLY ? (size_t)sd.nphase * 12 * 8 : 0);
+    const size_t per_wave = sizeof(WaveState) + (POLY ? (size_t)sd.nphase * 14 * 8 : 0);
     const size_t shmem = 4 * per_wave;
     auto kfn = zspace_kernel<NPL, POLY>;
     if (shmem > 48 * 1024) {

@@ -21,7 +21,7 @@ MODE_AUTO, MODE_DENSE = 0, 1
 # every symbol include/mpc_amd.h declares
 EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constraints",
            "mpcb_solve_coupled_device", "mpcb_solve_coupled", "mpcb_solve_box_device",
-           "mpcb_solve_box", "mpcb_get_matrix")
+           "mpcb_solve_box", "mpcb_get_matrix", "mpcb_replan_sweep_device")
 
 
 class Params(C.Structure):
@@ -36,6 +36,11 @@ class Params(C.Structure):
 class CoupledInputs(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in
                 ("x0", "y0", "speed", "feet_x", "feet_y", "swing0", "com0")]
+
+
+class ReplanState(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in
+                ("x0", "y0", "speed", "feet_x", "feet_y", "swing0", "com0", "disturbance")]
 
 
 _OUT_F64 = ("jerk_x", "jerk_y", "com_x", "com_y", "com_xd", "com_yd", "zmp_x", "zmp_y",
@@ -70,6 +75,9 @@ def load_library():
         lib.mpcb_solve_box_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_get_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.mpcb_replan_sweep_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                 C.POINTER(ReplanState), C.POINTER(Outputs), C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -237,3 +245,40 @@ class BatchedPlanner:
         """solveQPconstraint for B one-axis instances; results are in the *_x outputs."""
         return self.solve_box_prepared(self.prepare_box(x0, zmin, zmax), outputs=outputs,
                                        stream=stream)
+
+    # -- receding-horizon sweep ---------------------------------------------------
+    def prepare_replanning(self, x0, y0, speed, feet_x, feet_y, swing0, disturbance=None, **_):
+        """Uploads the initial state of B rollouts (copied: the sweep updates it in place)."""
+        f64, i32 = self._torch.float64, self._torch.int32
+        ts = dict(x0=self._dev(x0, f64).clone(), y0=self._dev(y0, f64).clone(),
+                  speed=self._dev(speed, f64), feet_x=self._dev(feet_x, f64).clone(),
+                  feet_y=self._dev(feet_y, f64).clone(), swing0=self._dev(swing0, i32).clone(),
+                  disturbance=self._dev(disturbance, f64))
+        B = ts["x0"].shape[0]
+        ts["com0"] = self._torch.zeros((B, 2), dtype=f64, device=self.device)
+        rs = ReplanState()
+        for k, t in ts.items():
+            if t is not None:
+                setattr(rs, k, t.data_ptr())
+        return B, rs, ts
+
+    def replan_sweep(self, prepared, n_stages, use_com_correction=True, disturbance_start=4,
+                     outputs=DEFAULT_OUTPUTS, out=None, record=True, stream=None):
+        """n_stages dependent replans of every rollout, entirely on the device.  Returns
+        (last-stage outputs, per-stage dict(cost, status, n_active), evolved state tensors)."""
+        torch = self._torch
+        B, rs, ts = prepared
+        if out is None:
+            out = self._alloc_outputs(B, outputs)
+        res, o = out
+        stage = None
+        ptrs = [None, None, None]
+        if record:
+            stage = dict(cost=torch.empty((n_stages, B), dtype=torch.float64, device=self.device),
+                         status=torch.empty((n_stages, B), dtype=torch.int32, device=self.device),
+                         n_active=torch.empty((n_stages, B), dtype=torch.int32, device=self.device))
+            ptrs = [stage["cost"].data_ptr(), stage["status"].data_ptr(), stage["n_active"].data_ptr()]
+        _check(load_library().mpcb_replan_sweep_device(self._h, B, int(n_stages), int(use_com_correction),
+                                                       int(disturbance_start), C.byref(rs), C.byref(o),
+                                                       ptrs[0], ptrs[1], ptrs[2], self._stream(stream)))
+        return res, stage, ts

@@ -1273,6 +1273,95 @@ int orc_coupled_batch(const orc_params *p, int variant, int steps, int rw, int B
     return 0;
 }
 
+int orc_replanning_batch(const orc_params *p, int steps, int n_stages, int use_com_correction,
+                         const double *hip, int B, double *x0, double *y0, const double *speed,
+                         double *feet_x, double *feet_y, int *swing0, const double *disturbance,
+                         int disturbance_start, double *stage_cost, int *stage_status,
+                         int *stage_nactive, double *jerk_x, double *jerk_y, int nthreads) {
+    const int N = p->N;
+    const int rw = N / steps; /* replanningWindow (testPlannerXYconstraintMPC.cpp:95) */
+    const double zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!hip) hip = zero8;
+    std::vector<int> err(std::max(1, nthreads), 0);
+    parallel_for(B, nthreads, [&](int lo, int hi, int tid) {
+        Planner pl = make_planner(p);
+        for (int i = lo; i < hi; i++) {
+            double sx[3] = {x0[3 * i], x0[3 * i + 1], x0[3 * i + 2]};
+            double sy[3] = {y0[3 * i], y0[3 * i + 1], y0[3 * i + 2]};
+            double fx[4], fy[4];
+            for (int l = 0; l < 4; l++) {
+                fx[l] = feet_x[4 * i + l];
+                fy[l] = feet_y[4 * i + l];
+            }
+            FootScheduler sched;
+            sched.setSequence(ORC_LF, ORC_RH, ORC_RF, ORC_LH); /* :45 */
+            sched.setCurrentSwing(swing0[i]);
+            FootState fs[4], holds[4];
+            Vec jx(N, 0.0), jy(N, 0.0);
+            int sampleW = 0;
+            for (int sample = 0; sample < n_stages * rw; sample++) {
+                if (sample % rw == 0) { /* :112 */
+                    const int stage = sample / rw;
+                    if (sample > 0) { /* :117-134 */
+                        for (int l = 0; l < 4; l++) {
+                            fx[l] = fs[l].x[sampleW];
+                            fy[l] = fs[l].y[sampleW];
+                        }
+                        sched.next();
+                    }
+                    Mat Ap;
+                    Vec bv;
+                    const double zero2[2] = {0, 0};
+                    const double com[2] = {sx[0], sy[0]};
+                    int m = pl.computeSteps(speed + 2 * (size_t)i, fx, fy, steps, N, fs, holds, Ap, bv,
+                                            sched.getCurrentSwing(), use_com_correction ? com : zero2, hip);
+                    if (m < 0) {
+                        err[tid] = m;
+                        return;
+                    }
+                    std::vector<int> act(m + 1);
+                    orc_info li;
+                    pl.solveCoupled(ORC_COUPLED_VEL, p->height, sx, sy, nullptr, nullptr, Ap, bv,
+                                    speed + 2 * (size_t)i, rw, jx, jy, &li, act.data());
+                    if (stage_cost) stage_cost[(size_t)stage * B + i] = li.f;
+                    if (stage_status) stage_status[(size_t)stage * B + i] = li.status;
+                    if (stage_nactive) stage_nactive[(size_t)stage * B + i] = li.n_active;
+                    sampleW = 0;
+                } else
+                    sampleW++;
+                /* :206-207 computeCOMupdate */
+                const double ux = jx[sampleW];
+                const double uy = jy[sampleW] + (sample >= disturbance_start ? disturbance[i] : 0.0);
+                double nx[3], ny[3];
+                for (int r3 = 0; r3 < 3; r3++) {
+                    nx[r3] = (pl.A[r3][0] * sx[0] + pl.A[r3][1] * sx[1] + pl.A[r3][2] * sx[2]) + pl.B[r3] * ux;
+                    ny[r3] = (pl.A[r3][0] * sy[0] + pl.A[r3][1] * sy[1] + pl.A[r3][2] * sy[2]) + pl.B[r3] * uy;
+                }
+                for (int r3 = 0; r3 < 3; r3++) {
+                    sx[r3] = nx[r3];
+                    sy[r3] = ny[r3];
+                }
+            }
+            /* state the next replan would start from */
+            for (int l = 0; l < 4; l++) {
+                feet_x[4 * i + l] = fs[l].x[sampleW];
+                feet_y[4 * i + l] = fs[l].y[sampleW];
+            }
+            sched.next();
+            swing0[i] = sched.getCurrentSwing();
+            for (int r3 = 0; r3 < 3; r3++) {
+                x0[3 * i + r3] = sx[r3];
+                y0[3 * i + r3] = sy[r3];
+            }
+            if (jerk_x) std::copy(jx.begin(), jx.end(), jerk_x + (size_t)i * N);
+            if (jerk_y) std::copy(jy.begin(), jy.end(), jerk_y + (size_t)i * N);
+        }
+    });
+    for (int e : err)
+        if (e) return e;
+    return 0;
+}
+
 int orc_box_batch(const orc_params *p, int B, const double *x0, const double *y0,
                   const double *xmin, const double *xmax, const double *ymin, const double *ymax,
                   double *jerk_x, double *jerk_y, double *cost, int *status, int *n_active,

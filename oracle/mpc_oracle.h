@@ -140,6 +140,23 @@ int orc_coupled_batch(const orc_params *p, int variant, int steps, int rw,
                       int *status, int *n_active, int *active, int active_stride,
                       int *iters, double *falg, int nthreads);
 
+/* Receding-horizon replanning of B rollouts, the loop of
+ * tests/replanning/testPlannerXYconstraintMPC.cpp:108-209 with optimizeVelocity on:
+ * every replanningWindow = floor(N/steps) samples the feet are taken from knot
+ * sampleW of the previous plan, the schedule advances, computeSteps runs from the
+ * actual CoM (step correction if use_com_correction), the velocity formulation is
+ * solved with the Gaussian weights of that window, and the state is integrated with
+ * computeCOMupdate; the Y jerk is disturbed by disturbance[i] from sample
+ * disturbance_start on.  An infeasible stage contributes zero jerk.
+ * In/out: x0, y0 [B][3], feet_x, feet_y [B][4], swing0 [B].
+ * Out (may be NULL): stage_cost/stage_status/stage_nactive [n_stages][B],
+ * last-stage jerk_x/jerk_y [B][N]. */
+int orc_replanning_batch(const orc_params *p, int steps, int n_stages, int use_com_correction,
+                         const double *hip, int B, double *x0, double *y0, const double *speed,
+                         double *feet_x, double *feet_y, int *swing0, const double *disturbance,
+                         int disturbance_start, double *stage_cost, int *stage_status,
+                         int *stage_nactive, double *jerk_x, double *jerk_y, int nthreads);
+
 /* Same for X/Y pairs of box-constrained QPs. limits are [B][N]. */
 int orc_box_batch(const orc_params *p, int B, const double *x0, const double *y0,
                   const double *xmin, const double *xmax, const double *ymin,

@@ -232,3 +232,26 @@ def box_batch(p, x0, y0, xmin, xmax, ymin, ymax, active_stride=64, nthreads=1):
                         _p(out["n_active"]), _p(out["active"]), active_stride, _p(out["iters"]),
                         _p(out["falg"]), nthreads)
     return out
+
+
+def replanning_batch(p, steps, n_stages, x0, y0, speed, feet_x, feet_y, swing0, disturbance,
+                     disturbance_start=4, use_com_correction=True, hip=None, nthreads=1):
+    """The replanning driver's loop for a batch of rollouts.  Returns the evolved state
+    (x0, y0, feet_x, feet_y, swing0), per-stage cost/status/n_active and the last plan."""
+    x0, y0, speed, feet_x, feet_y = (_d(a).copy() for a in (x0, y0, speed, feet_x, feet_y))
+    swing0 = np.ascontiguousarray(swing0, dtype=np.int32).copy()
+    disturbance = _d(disturbance)
+    hip_a = _d(hip).reshape(8) if hip is not None else None
+    B, N = x0.shape[0], p.N
+    out = dict(stage_cost=np.zeros((n_stages, B)), stage_status=np.zeros((n_stages, B), dtype=np.int32),
+               stage_nactive=np.zeros((n_stages, B), dtype=np.int32), jerk_x=np.zeros((B, N)),
+               jerk_y=np.zeros((B, N)))
+    rc = lib().orc_replanning_batch(C.byref(p), steps, n_stages, int(use_com_correction), _p(hip_a), B,
+                                    _p(x0), _p(y0), _p(speed), _p(feet_x), _p(feet_y), _p(swing0),
+                                    _p(disturbance), int(disturbance_start), _p(out["stage_cost"]),
+                                    _p(out["stage_status"]), _p(out["stage_nactive"]),
+                                    _p(out["jerk_x"]), _p(out["jerk_y"]), nthreads)
+    if rc:
+        raise ValueError("orc_replanning_batch failed: %d" % rc)
+    out.update(x0=x0, y0=y0, feet_x=feet_x, feet_y=feet_y, swing0=swing0)
+    return out
