@@ -168,6 +168,11 @@ int  mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const dou
 int  mpcb_solve_box(mpcb_handle h, int32_t B, const double *x0, const double *zmin,
                     const double *zmax, const mpcb_outputs *out);
 
+/* Unconstrained ZMP tracking: solveQP (MPCPlanner.cpp:223-237) for B instances.
+ * x0 [B][3], zmp_ref [B][N].  Outputs: jerk_x, zmp_x, com_x, com_xd (status = OK). */
+int  mpcb_solve_unconstrained_device(mpcb_handle h, int32_t B, const double *x0, const double *zmp_ref,
+                                     const mpcb_outputs *out, void *stream);
+
 /* Copy an instance-independent matrix to the host (tests, diagnostics).
  * which: 0 = S (ZMP response, N x N), 1 = W^T (jerk response), 2 = CoM position
  * response, 3 = CoM velocity response, 4 = Kz (N x 4), 5 = Kx (N x 4).      */

@@ -380,6 +380,16 @@ int mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const doub
     return solve_two_stage(h, di, *out, B, (hipStream_t)stream);
 }
 
+int mpcb_solve_unconstrained_device(mpcb_handle h, int32_t B, const double *x0, const double *zmp_ref,
+                                    const mpcb_outputs *out, void *stream) {
+    if (!h || !x0 || !zmp_ref || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
+    if (h->params.formulation != MPCB_UNCONSTRAINED)
+        return fail(MPCB_E_ARG, "handle was not created for UNCONSTRAINED");
+    DeviceGuard guard(h->params.device);
+    HIP_TRY(mpcb::launch_unconstrained(h->ds, x0, zmp_ref, *out, B, (hipStream_t)stream));
+    return 0;
+}
+
 int mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, const mpcb_outputs *out) {
     if (!h || !in || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
     DeviceGuard guard(h->params.device);

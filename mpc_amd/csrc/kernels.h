@@ -60,6 +60,10 @@ hipError_t launch_list_all(const DenseWs &ws, int B, hipStream_t stream);
 hipError_t launch_dense(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, const DenseWs &ws,
                         int blocks, hipStream_t stream);
 
+// MPCPlanner::solveQP for B instances (handle built with MPCB_UNCONSTRAINED).
+hipError_t launch_unconstrained(const DevSetup &sd, const double *x0, const double *zref,
+                                const mpcb_outputs &out, int B, hipStream_t stream);
+
 // Receding-horizon sweep: mutable per-rollout state and the per-stage arguments of the
 // advance kernel.
 struct ReplanState {

@@ -21,7 +21,8 @@ MODE_AUTO, MODE_DENSE = 0, 1
 # every symbol include/mpc_amd.h declares
 EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constraints",
            "mpcb_solve_coupled_device", "mpcb_solve_coupled", "mpcb_solve_box_device",
-           "mpcb_solve_box", "mpcb_get_matrix", "mpcb_replan_sweep_device")
+           "mpcb_solve_box", "mpcb_get_matrix", "mpcb_replan_sweep_device",
+           "mpcb_solve_unconstrained_device")
 
 
 class Params(C.Structure):
@@ -75,6 +76,8 @@ def load_library():
         lib.mpcb_solve_box_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_get_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.mpcb_solve_unconstrained_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                                        C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_replan_sweep_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                  C.POINTER(ReplanState), C.POINTER(Outputs), C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]
@@ -245,6 +248,19 @@ class BatchedPlanner:
         """solveQPconstraint for B one-axis instances; results are in the *_x outputs."""
         return self.solve_box_prepared(self.prepare_box(x0, zmin, zmax), outputs=outputs,
                                        stream=stream)
+
+    def solve_unconstrained(self, x0, zmp_ref, outputs=("jerk_x", "zmp_x", "com_x", "com_xd", "status"),
+                            stream=None):
+        """solveQP for B instances: tracks zmp_ref [B, horizon] from x0 [B, 3]."""
+        f64 = self._torch.float64
+        tx, tz = self._dev(x0, f64), self._dev(zmp_ref, f64)
+        B = tx.shape[0]
+        if tuple(tx.shape) != (B, 3) or tuple(tz.shape) != (B, self.horizon):
+            raise ValueError("x0 must be [B,3] and zmp_ref [B,horizon]")
+        res, o = self._alloc_outputs(B, outputs)
+        _check(load_library().mpcb_solve_unconstrained_device(self._h, B, tx.data_ptr(), tz.data_ptr(),
+                                                              C.byref(o), self._stream(stream)))
+        return res
 
     # -- receding-horizon sweep ---------------------------------------------------
     def prepare_replanning(self, x0, y0, speed, feet_x, feet_y, swing0, disturbance=None, **_):
