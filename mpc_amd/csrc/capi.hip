@@ -285,6 +285,7 @@ int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_input
     const int form = h->params.formulation;
     if (form != MPCB_COUPLED_JERK && form != MPCB_COUPLED_VEL && form != MPCB_COUPLED_REF)
         return fail(MPCB_E_ARG, "handle was not created for a coupled formulation");
+    if (B == 0) return 0;
     if (!in->x0 || !in->y0 || !in->speed || !in->feet_x || !in->feet_y || !in->swing0)
         return fail(MPCB_E_ARG, "missing coupled input array");
     if ((out->active_idx || out->multipliers) && out->active_stride <= 0)
@@ -366,8 +367,9 @@ int mpcb_replan_sweep_device(mpcb_handle h, int32_t B, int32_t n_stages, int32_t
 
 int mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const double *zmin,
                           const double *zmax, const mpcb_outputs *out, void *stream) {
-    if (!h || !x0 || !zmin || !zmax || !out || B < 0)
-        return fail(MPCB_E_ARG, "null argument or negative batch");
+    if (!h || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
+    if (B == 0) return 0;
+    if (!x0 || !zmin || !zmax) return fail(MPCB_E_ARG, "null input array");
     if (h->params.formulation != MPCB_BOX_1D) return fail(MPCB_E_ARG, "handle was not created for BOX_1D");
     if ((out->active_idx || out->multipliers) && out->active_stride <= 0)
         return fail(MPCB_E_ARG, "active_stride must be positive");
@@ -382,7 +384,9 @@ int mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const doub
 
 int mpcb_solve_unconstrained_device(mpcb_handle h, int32_t B, const double *x0, const double *zmp_ref,
                                     const mpcb_outputs *out, void *stream) {
-    if (!h || !x0 || !zmp_ref || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
+    if (!h || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
+    if (B == 0) return 0;
+    if (!x0 || !zmp_ref) return fail(MPCB_E_ARG, "null input array");
     if (h->params.formulation != MPCB_UNCONSTRAINED)
         return fail(MPCB_E_ARG, "handle was not created for UNCONSTRAINED");
     DeviceGuard guard(h->params.device);
