@@ -262,6 +262,13 @@ void mpcb_destroy(mpcb_handle h) {
 
 int mpcb_num_constraints(mpcb_handle h) { return h ? h->hs.m : MPCB_E_ARG; }
 
+// Diagnostic builds (-DMPCB_STAMPS): device buffer of 10 cycle counters per instance.
+int mpcb_debug_set_stamp_buffer(mpcb_handle h, long long *dev) {
+    if (!h) return MPCB_E_ARG;
+    h->ds.dbg = dev;
+    return 0;
+}
+
 int mpcb_get_matrix(mpcb_handle h, int32_t which, double *dst) {
     if (!h || !dst) return fail(MPCB_E_ARG, "null argument");
     const mpcb::HostSetup &hs = h->hs;

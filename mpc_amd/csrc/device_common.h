@@ -25,28 +25,70 @@ __device__ __forceinline__ double ufirst(double v) {
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return ufirst(v);
+// Cross-lane reductions on DPP (data-parallel primitives: lane permutes inside the VALU,
+// no LDS crossbar).  All 64 lanes must be active.  Control codes (gfx9): quad_perm 0x00-0xFF,
+// row_half_mirror 0x141, row_mirror 0x140, row_bcast15 0x142, row_bcast31 0x143.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
 }
 
-// Minimum of (val, key); the smaller key wins ties.  Result is wave-uniform.
+__device__ __forceinline__ double lane63(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the wave; the result is wave-uniform.  Butterfly inside each row of 16 lanes,
+// then row totals are chained into lane 63.
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_f64<0xB1, 0xF>(v, v);  // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xF>(v, v);  // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141, 0xF>(v, v); // row_half_mirror
+    v += dpp_f64<0x140, 0xF>(v, v); // row_mirror
+    v += dpp_f64<0x142, 0xA>(0.0, v); // row_bcast15 -> rows 1, 3
+    v += dpp_f64<0x143, 0xC>(0.0, v); // row_bcast31 -> rows 2, 3
+    return lane63(v);
+}
+
+// NaN-ignoring minimum (fmin), like the reference's `<` comparisons that never pick a NaN.
+__device__ __forceinline__ double wave_min(double v) {
+    v = fmin(v, dpp_f64<0xB1, 0xF>(v, v));
+    v = fmin(v, dpp_f64<0x4E, 0xF>(v, v));
+    v = fmin(v, dpp_f64<0x141, 0xF>(v, v));
+    v = fmin(v, dpp_f64<0x140, 0xF>(v, v));
+    v = fmin(v, dpp_f64<0x142, 0xA>(DINF, v));
+    v = fmin(v, dpp_f64<0x143, 0xC>(DINF, v));
+    return lane63(v);
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+    v = min(v, dpp_i32<0xB1, 0xF>(v, v));
+    v = min(v, dpp_i32<0x4E, 0xF>(v, v));
+    v = min(v, dpp_i32<0x141, 0xF>(v, v));
+    v = min(v, dpp_i32<0x140, 0xF>(v, v));
+    v = min(v, dpp_i32<0x142, 0xA>(0x7fffffff, v));
+    v = min(v, dpp_i32<0x143, 0xC>(0x7fffffff, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Minimum of (val, key) over the wave; the smaller key wins ties; aux travels with the
+// winner.  Results are wave-uniform.  A lane without a candidate passes val = +inf.
 __device__ __forceinline__ void wave_argmin(double &val, int &key, int &aux) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(val, o, 64);
-        const int ok = __shfl_xor(key, o, 64);
-        const int oa = __shfl_xor(aux, o, 64);
-        if (ov < val || (ov == val && ok < key)) {
-            val = ov;
-            key = ok;
-            aux = oa;
-        }
-    }
-    val = ufirst(val);
-    key = ufirst(key);
-    aux = ufirst(aux);
+    const double m = wave_min(val);
+    const bool cand = val == m;
+    const int k = wave_min(cand ? key : 0x7fffffff);
+    const unsigned long long win = __ballot(cand && key == k);
+    const int src = win ? __ffsll((long long)win) - 1 : 0;
+    aux = __builtin_amdgcn_readlane(aux, src);
+    val = m;
+    key = k;
 }
 
 // eiquadprog.hpp:90-108

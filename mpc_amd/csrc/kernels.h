@@ -27,6 +27,7 @@ struct DevSetup {
     double psi_thr;                   // m * eps * c1 * c2 * 100 (eiquadprog.hpp:267)
     double traceG1;
     double hip[8];
+    long long *dbg;                   // cycle stamps (diagnostic builds only), else NULL
 };
 
 struct DevIn {

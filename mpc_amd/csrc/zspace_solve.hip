@@ -35,10 +35,11 @@ struct WaveState {
     double Rinv[TRI];
     double wsU[QL + 1], wsP[QL + 1], wsQ[QL + 1];       // working set: multiplier, p, q
     double oldU[QL + 1], oldP[QL + 1], oldQ[QL + 1];    // copy taken at step 1 (eiquadprog.hpp:275-277)
-    double g[QL + 1], d[QL + 1], cx[QL + 1], cy[QL + 1];
-    int wsRow[QL + 1], wsKS[QL + 1];                    // constraint row; (knot << 2) | slot
+    double g[QL + 1], d[QL + 1];
+    double cx[QL + 4], cy[QL + 4];                      // row coefficients, zero-padded to a multiple of 4
+    int wsRow[QL + 1], wsKS[QL + 4];                    // constraint row; (knot << 2) | slot
     int oldRow[QL + 1], oldKS[QL + 1];
-    int pad[4];
+    int pad[3];
 };
 static_assert(sizeof(WaveState) % 8 == 0, "tab must stay 8-byte aligned");
 
@@ -123,6 +124,21 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
     wsync();
 }
 
+// Diagnostic build only (-DMPCB_STAMPS): cycles per section, summed per instance into
+// sd.dbg[inst*10 + section].  No stamp executes in the normal build.
+#ifdef MPCB_STAMPS
+#define STAMP(i)                                         \
+    do {                                                 \
+        const long long t_ = __builtin_amdgcn_s_memtime(); \
+        stamp_acc[i] += t_ - stamp_t;                    \
+        stamp_t = t_;                                    \
+    } while (0)
+#else
+#define STAMP(i) \
+    do {         \
+    } while (0)
+#endif
+
 template <int NPL, bool POLY>
 __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
                                                       int *unresolved_list, int *unresolved_count) {
@@ -133,6 +149,10 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
     const int inst = ufirst((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (inst >= B) return;
     const int N = sd.N;
+#ifdef MPCB_STAMPS
+    long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
     const int tab_doubles = POLY ? sd.nphase * 14 : 0;
     const int per_wave = (int)(sizeof(WaveState) / 8) + tab_doubles;
     WaveState &W = *reinterpret_cast<WaveState *>(smem + (size_t)wv * per_wave);
@@ -199,7 +219,43 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
             }
         }
     }
+    if (lane < QL + 4) W.wsKS[lane] = 0; // padding entries must name a valid knot
     wsync();
+
+    // v += sum_a coef_a * M[knot_a, :] over the first n working-set rows, four rows'
+    // loads in flight at a time (cx/cy are zero beyond n, so the padding rows add 0)
+    auto accum_rows = [&](const double *M, int n, double *vx, double *vy) {
+        for (int a0 = 0; a0 < n; a0 += 4) {
+            const double *row[4];
+            double ca[4], cb[4], sv[4][NPL];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                row[j] = M + (size_t)(ufirst(W.wsKS[a0 + j]) >> 2) * N;
+                ca[j] = W.cx[a0 + j];
+                cb[j] = W.cy[a0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int c = 0; c < NPL; c++) sv[j][c] = row[j][kc[c]];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int c = 0; c < NPL; c++) {
+                    vx[c] += ca[j] * sv[j][c];
+                    if constexpr (POLY) vy[c] += cb[j] * sv[j][c];
+                }
+        }
+    };
+    // coefficients of the working-set rows: coef * (p, q), zero-padded
+    auto set_coefs = [&](double coef, int n) {
+        if (lane < QL + 4) {
+            const bool in = lane < n;
+            W.cx[lane] = in ? coef * W.wsP[lane < QL ? lane : QL] : 0.0;
+            W.cy[lane] = in ? coef * W.wsQ[lane < QL ? lane : QL] : 0.0;
+        }
+        wsync();
+    };
 
     auto slotP = [&](int c, int e) -> double {
         if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3];
@@ -254,11 +310,13 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
     double falg = 2.0 * nn * nn;
     unsigned actm = 0, exclm = 0;
     double R_norm = 1.0;
-    double s[NPL][ES], zx[NPL], zy[NPL];
+    double zx[NPL], zy[NPL];
     bool pending = false;       // a candidate's partial steps are part of x (cap exit)
+    bool zmp_current = false;   // zx, zy hold the ZMP of the final multipliers
     int ipRow = 0, ipKS = 0;
     double pip = 0.0, qip = 0.0, ucand = 0.0, s_ip = 0.0;
 
+    STAMP(0);
     for (;;) { // step 1 (l1)
         iters++;
         if (iters > sd.iter_cap) {
@@ -266,41 +324,55 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
             break;
         }
         // zmp at x = x_unc + G^-1 N_A u
-        if (lane < iq) {
-            W.cx[lane] = W.wsU[lane] * W.wsP[lane];
-            W.cy[lane] = W.wsU[lane] * W.wsQ[lane];
-        }
-        wsync();
+        set_coefs(lane < iq ? W.wsU[lane] : 0.0, iq);
 #pragma unroll
         for (int c = 0; c < NPL; c++) {
             zx[c] = zxu[c];
             zy[c] = zyu[c];
         }
-        for (int a = 0; a < iq; a++) {
-            const int ka = ufirst(W.wsKS[a]) >> 2;
-            const double ca = W.cx[a], cb = W.cy[a];
-            const double *srow = sd.S + (size_t)ka * N;
-#pragma unroll
-            for (int c = 0; c < NPL; c++) {
-                const double sv = srow[kc[c]];
-                zx[c] += ca * sv;
-                if constexpr (POLY) zy[c] += cb * sv;
-            }
-        }
+        accum_rows(sd.S, iq, zx, zy);
+        STAMP(1);
+        // s(x) for every row (:255-261), fused with the search for the most violated row
+        // (step 2, :279-287, first pass: ss = 0).  Row values are not kept: the rare
+        // restart of step 2 recomputes them from zx, zy.
         double psi = 0.0;
+        double bv0 = DINF;
+        int brow0 = 0x7fffffff, bks0 = 0;
+        {
+            // every slot's (p, q, r) is loaded first and unconditionally (slots that do not
+            // exist read a valid but meaningless table entry and are masked below), so the
+            // LDS reads overlap instead of serialising behind per-slot branches
+            double sp[NPL][ES], sq[NPL][ES], sr[NPL][ES];
 #pragma unroll
-        for (int c = 0; c < NPL; c++)
+            for (int c = 0; c < NPL; c++)
 #pragma unroll
-            for (int e = 0; e < ES; e++) {
-                double v = DINF;
-                if (validm & (1u << (4 * c + e))) v = slotP(c, e) * zx[c] + slotQ(c, e) * zy[c] + slotR(c, e);
-                s[c][e] = v;
-                psi += fmin(0.0, v);
-            }
+                for (int e = 0; e < ES; e++) {
+                    sp[c][e] = slotP(c, e);
+                    sq[c][e] = slotQ(c, e);
+                    sr[c][e] = slotR(c, e);
+                }
+#pragma unroll
+            for (int c = 0; c < NPL; c++)
+#pragma unroll
+                for (int e = 0; e < ES; e++) {
+                    const unsigned bit = 1u << (4 * c + e);
+                    const bool valid = (validm & bit) != 0;
+                    const double v = valid ? sp[c][e] * zx[c] + sq[c][e] * zy[c] + sr[c][e] : DINF;
+                    psi += fmin(0.0, v);
+                    const int row = slotRow(c, e);
+                    const bool better = !(actm & bit) && v < 0.0 && (v < bv0 || (v == bv0 && row < brow0));
+                    bv0 = better ? v : bv0;
+                    brow0 = better ? row : brow0;
+                    bks0 = better ? ((kn[c] << 2) | e) : bks0;
+                }
+        }
         psi = wave_sum(psi);
         falg += 2.0 * mm * nn;
         exclm = 0xffffffffu; // iaexcl[i] = true (:257)
-        if (fabs(psi) <= sd.psi_thr) break; // :267-272
+        if (fabs(psi) <= sd.psi_thr) { // :267-272
+            zmp_current = true;
+            break;
+        }
         if (lane < iq) { // :275-277
             W.oldU[lane] = W.wsU[lane];
             W.oldP[lane] = W.wsP[lane];
@@ -308,26 +380,37 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
             W.oldRow[lane] = W.wsRow[lane];
             W.oldKS[lane] = W.wsKS[lane];
         }
+        STAMP(2);
         double ssv = 0.0;
-        bool done = false, restart;
+        bool done = false, restart, restart_seen = false;
         do { // step 2 (l2), :279-299
             restart = false;
-            double bv = DINF;
-            int brow = 0x7fffffff, bks = 0;
+            double bv = bv0;
+            int brow = brow0, bks = bks0;
+            if (restart_seen) {
+                // second pass of step 2 after a degenerate add: rows below the running
+                // minimum ss that are neither active nor excluded
+                bv = DINF;
+                brow = 0x7fffffff;
+                bks = 0;
 #pragma unroll
-            for (int c = 0; c < NPL; c++)
+                for (int c = 0; c < NPL; c++)
 #pragma unroll
-                for (int e = 0; e < ES; e++) {
-                    const unsigned bit = 1u << (4 * c + e);
-                    const int row = slotRow(c, e);
-                    if ((validm & bit) && !(actm & bit) && (exclm & bit) && s[c][e] < ssv &&
-                        (s[c][e] < bv || (s[c][e] == bv && row < brow))) {
-                        bv = s[c][e];
-                        brow = row;
-                        bks = (kn[c] << 2) | e;
+                    for (int e = 0; e < ES; e++) {
+                        const unsigned bit = 1u << (4 * c + e);
+                        if ((validm & bit) && !(actm & bit) && (exclm & bit)) {
+                            const double v = slotP(c, e) * zx[c] + slotQ(c, e) * zy[c] + slotR(c, e);
+                            const int row = slotRow(c, e);
+                            if (v < ssv && (v < bv || (v == bv && row < brow))) {
+                                bv = v;
+                                brow = row;
+                                bks = (kn[c] << 2) | e;
+                            }
+                        }
                     }
-                }
+            }
             wave_argmin(bv, brow, bks);
+            STAMP(3);
             if (bv < ssv) {
                 ssv = bv;
                 ipRow = brow;
@@ -335,6 +418,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                 s_ip = bv;
             }
             if (ssv >= 0.0) {
+                zmp_current = !restart_seen; // after a degenerate restart u was restored, zx is stale
                 done = true;
                 break;
             }
@@ -368,35 +452,40 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                 }
                 W.g[lane < QL ? lane : QL] = ga;
                 wsync();
+                STAMP(4);
                 {
-                    const int off = tri(lane);
+                    // loads are unconditional (clamped addresses) so they can be issued ahead
+                    const int lq = lane < QL ? lane : QL - 1;
+                    const int off = tri(lq);
+#pragma unroll 4
                     for (int j = 0; j < iq; j++) {
                         const double gj = W.g[j];
-                        if (lane < iq && j <= lane) da += W.Rinv[off + j] * gj;
+                        const double rv = W.Rinv[off + (j <= lq ? j : lq)];
+                        da += (lane < iq && j <= lane) ? rv * gj : 0.0;
+                    }
+                    W.d[lane < QL ? lane : QL] = da;
+                    wsync();
+#pragma unroll 4
+                    for (int k = 0; k < iq; k++) {
+                        const double dk = W.d[k];
+                        const double rv = W.Rinv[tri(k) + (lq <= k ? lq : k)];
+                        ra += (lane < iq && k >= lane) ? rv * dk : 0.0;
                     }
                 }
-                W.d[lane < QL ? lane : QL] = da;
-                wsync();
-                for (int k = 0; k < iq; k++) {
-                    const double dk = W.d[k];
-                    if (lane < iq && k >= lane) ra += W.Rinv[tri(k) + lane] * dk;
-                }
+                STAMP(5);
                 const double zn = mii - wave_sum(da * da); // z . n_ip
                 // step 2b: t1 = min u_k / r_k over r_k > 0, first minimum wins (:322-334)
                 double t1 = (lane < iq && ra > 0.0) ? ua / ra : DINF;
                 int apos = lane, dummy = 0;
                 wave_argmin(t1, apos, dummy);
+                STAMP(6);
                 // z != 0 test (:336): ||z||^2 >= zn / lambda_max(G1) >= zn / trace(G1)
                 bool znz;
                 if (zn > 1e-8 * mii && zn > 64.0 * EPS * sd.traceG1) {
                     znz = true;
                 } else {
                     // explicit z = G^-1 (n_ip - N_A r)
-                    if (lane < iq) {
-                        W.cx[lane] = ra * W.wsP[lane];
-                        W.cy[lane] = ra * W.wsQ[lane];
-                    }
-                    wsync();
+                    set_coefs(-ra, iq);
                     double acc = 0.0;
                     double zvx[NPL], zvy[NPL];
                     const double *wip = sd.Wt + (size_t)kip * N;
@@ -406,17 +495,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                         zvx[c] = pip * w;
                         zvy[c] = qip * w;
                     }
-                    for (int a = 0; a < iq; a++) {
-                        const int ka = ufirst(W.wsKS[a]) >> 2;
-                        const double ca = W.cx[a], cb = W.cy[a];
-                        const double *wrow = sd.Wt + (size_t)ka * N;
-#pragma unroll
-                        for (int c = 0; c < NPL; c++) {
-                            const double w = wrow[kc[c]];
-                            zvx[c] -= ca * w;
-                            zvy[c] -= cb * w;
-                        }
-                    }
+                    accum_rows(sd.Wt, iq, zvx, zvy);
 #pragma unroll
                     for (int c = 0; c < NPL; c++)
                         if (kn[c] < N) acc += zvx[c] * zvx[c] + zvy[c] * zvy[c];
@@ -483,6 +562,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                         }
                         pending = false;
                         restart = true;
+                        restart_seen = true;
                         break;
                     }
                     R_norm = fmax(R_norm, rho);
@@ -519,8 +599,10 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                 drop_constraint(W, lane, iq, apos);
             }
         } while (restart);
+        STAMP(7);
         if (done) break;
     }
+    STAMP(7);
 
     // ---- outputs -------------------------------------------------------------
     const bool solved = status == MPCB_OK || status == MPCB_ITER_CAP;
@@ -542,19 +624,17 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
     }
     // multipliers -> trajectories through the response matrices
     int nresp = iq;
-    if (lane < iq) {
-        W.cx[lane] = W.wsU[lane] * W.wsP[lane];
-        W.cy[lane] = W.wsU[lane] * W.wsQ[lane];
-    }
+    set_coefs(lane < iq ? W.wsU[lane] : 0.0, iq);
     if (pending && status == MPCB_ITER_CAP && iq < QL) {
+        // partial steps of an unfinished candidate are part of x
         if (lane == 0) {
             W.cx[iq] = ucand * pip;
             W.cy[iq] = ucand * qip;
             W.wsKS[iq] = ipKS;
         }
         nresp = iq + 1;
+        wsync();
     }
-    wsync();
     auto respond = [&](const double *K, const double *M, const double *Mp, double *ox, double *oy) {
         if (!ox && !oy) return;
         double vx[NPL], vy[NPL];
@@ -576,17 +656,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                     }
                 }
         }
-        for (int a = 0; a < nresp; a++) {
-            const int ka = ufirst(W.wsKS[a]) >> 2;
-            const double ca = W.cx[a], cb = W.cy[a];
-            const double *mrow = M + (size_t)ka * N;
-#pragma unroll
-            for (int c = 0; c < NPL; c++) {
-                const double mv = mrow[kc[c]];
-                vx[c] += ca * mv;
-                vy[c] += cb * mv;
-            }
-        }
+        accum_rows(M, nresp, vx, vy);
 #pragma unroll
         for (int c = 0; c < NPL; c++)
             if (kn[c] < N) {
@@ -598,39 +668,36 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
     respond(sd.Kc, sd.Sc, sd.Scp, out.com_x, out.com_y);
     respond(sd.Kv, sd.Sv, sd.Svp, out.com_xd, out.com_yd);
     if (out.zmp_x || out.zmp_y || out.min_margin) {
-        double vx[NPL], vy[NPL];
-#pragma unroll
-        for (int c = 0; c < NPL; c++) {
-            vx[c] = zxu[c];
-            vy[c] = zyu[c];
-        }
-        for (int a = 0; a < nresp; a++) {
-            const int ka = ufirst(W.wsKS[a]) >> 2;
-            const double ca = W.cx[a], cb = W.cy[a];
-            const double *srow = sd.S + (size_t)ka * N;
+        // On a regular exit zx, zy were evaluated at the final multipliers in step 1.
+        if (!zmp_current) {
 #pragma unroll
             for (int c = 0; c < NPL; c++) {
-                const double sv = srow[kc[c]];
-                vx[c] += ca * sv;
-                vy[c] += cb * sv;
+                zx[c] = zxu[c];
+                zy[c] = zyu[c];
             }
+            accum_rows(sd.S, nresp, zx, zy);
         }
 #pragma unroll
         for (int c = 0; c < NPL; c++)
             if (kn[c] < N) {
-                if (out.zmp_x) out.zmp_x[(size_t)inst * N + kn[c]] = solved ? vx[c] : 0.0;
-                if (out.zmp_y) out.zmp_y[(size_t)inst * N + kn[c]] = solved ? vy[c] : 0.0;
+                if (out.zmp_x) out.zmp_x[(size_t)inst * N + kn[c]] = solved ? zx[c] : 0.0;
+                if (out.zmp_y) out.zmp_y[(size_t)inst * N + kn[c]] = solved ? zy[c] : 0.0;
                 if (out.min_margin) {
                     // getConstraintViolation (MPCPlanner.cpp:1132-1153)
                     double mn = DINF;
 #pragma unroll
                     for (int e = 0; e < ES; e++)
                         if (validm & (1u << (4 * c + e)))
-                            mn = fmin(mn, slotP(c, e) * vx[c] + slotQ(c, e) * vy[c] + slotR(c, e));
+                            mn = fmin(mn, slotP(c, e) * zx[c] + slotQ(c, e) * zy[c] + slotR(c, e));
                     out.min_margin[(size_t)inst * N + kn[c]] = solved ? mn : 0.0;
                 }
             }
     }
+#ifdef MPCB_STAMPS
+    STAMP(8);
+    if (lane == 0 && sd.dbg)
+        for (int i = 0; i < 10; i++) sd.dbg[(size_t)inst * 10 + i] = stamp_acc[i];
+#endif
 }
 
 template <int NPL, bool POLY>

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpc_amd.so")
+# MPC_AMD_LIB selects another build of the same library (e.g. the cycle-stamp build)
+LIB_PATH = os.environ.get("MPC_AMD_LIB") or os.path.join(_HERE, "libmpc_amd.so")
 
 BOX_1D, COUPLED_JERK, COUPLED_VEL, COUPLED_REF, UNCONSTRAINED = 0, 1, 2, 3, 4
 OK, INFEASIBLE, ITER_CAP = 0, 1, 2

@@ -104,8 +104,9 @@ def test_box_vs_oracle(P, oracle):
             na = ref["n_active"][i, ax]
             assert list(o["active_idx"][i, :o["n_active"][i]]) == list(ref["active"][i, ax, :na])
             assert _rel(o["jerk_x"][i], jr[i]) < RTOL
-            # the ZMP honours the box
-            assert (o["zmp_x"][i] >= lo[i] - 1e-9).all() and (o["zmp_x"][i] <= hi[i] + 1e-9).all()
+            # the ZMP honours the box up to the solver's stopping rule (sum of violations
+            # <= m * eps * trace(G) * trace(L^-T) * 100 = 4.4e-8 here, eiquadprog.hpp:267)
+            assert (o["zmp_x"][i] >= lo[i] - 1e-7).all() and (o["zmp_x"][i] <= hi[i] + 1e-7).all()
         assert (np.abs(o["cost"][ok] - ref["cost"][ok, ax]) <= RTOL * np.maximum(1e-12, np.abs(ref["cost"][ok, ax]))).all()
         # infeasible draws: zero-filled outputs, infinite cost
         bad = ~ok
