@@ -95,6 +95,15 @@ typedef struct {
     const double  *feet_y;    /* [B][4] initial_feet_y                                  */
     const int32_t *swing0;    /* [B]    swing_leg_index (LegID)                         */
     const double  *com0;      /* [B][2] initialCoM; (0,0) = no step correction; may be NULL */
+    /* Optional.  When rows_pqr is given the library does NOT run computeSteps: the polygon
+     * rows are the caller's, one (p, q, r) per row of the A, b that computeSteps returned
+     * (A(row, k) = p, A(row, k + N) = q, b(row) = r; MPCPlanner.cpp:1072-1079), in the same
+     * row order (mpcb_num_constraints rows); feet_x, feet_y, swing0, com0 are then unused. */
+    const double  *rows_pqr;  /* [B][m][3] or NULL                                       */
+    /* Optional ZMP reference for COUPLED_REF, constant over each phase of computeSteps
+     * (2*number_of_steps + 1 phases: four-stance, three-stance, ..., trailing knots);
+     * NULL = centroid of the stance feet (computeCentroid).  Required with rows_pqr.       */
+    const double  *zref_phase; /* [B][nphase][2] or NULL                                 */
 } mpcb_coupled_inputs;
 
 /* Outputs.  Any pointer may be NULL (that output is skipped). */
@@ -126,6 +135,8 @@ const char *mpcb_last_error(void);
 
 /* Number of inequality rows m of one instance (700 for N=200, 20 steps; 2N for BOX_1D). */
 int  mpcb_num_constraints(mpcb_handle h);
+/* Number of footstep phases of one coupled instance (2*number_of_steps + 1). */
+int  mpcb_num_phases(mpcb_handle h);
 
 /* Coupled XY plan: computeSteps -> [computeCentroid] -> solveQPConstraintCoupled[Ref]
  * -> getConstraintViolation -> computeZMP/COMtrajectory for B instances. */
@@ -172,6 +183,8 @@ int  mpcb_solve_box(mpcb_handle h, int32_t B, const double *x0, const double *zm
  * x0 [B][3], zmp_ref [B][N].  Outputs: jerk_x, zmp_x, com_x, com_xd (status = OK). */
 int  mpcb_solve_unconstrained_device(mpcb_handle h, int32_t B, const double *x0, const double *zmp_ref,
                                      const mpcb_outputs *out, void *stream);
+int  mpcb_solve_unconstrained(mpcb_handle h, int32_t B, const double *x0, const double *zmp_ref,
+                              const mpcb_outputs *out);
 
 /* Copy an instance-independent matrix to the host (tests, diagnostics).
  * which: 0 = S (ZMP response, N x N), 1 = W^T (jerk response), 2 = CoM position

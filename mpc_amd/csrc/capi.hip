@@ -261,6 +261,7 @@ void mpcb_destroy(mpcb_handle h) {
 }
 
 int mpcb_num_constraints(mpcb_handle h) { return h ? h->hs.m : MPCB_E_ARG; }
+int mpcb_num_phases(mpcb_handle h) { return h ? h->hs.nphase : MPCB_E_ARG; }
 
 // Diagnostic builds (-DMPCB_STAMPS): device buffer of 10 cycle counters per instance.
 int mpcb_debug_set_stamp_buffer(mpcb_handle h, long long *dev) {
@@ -293,8 +294,11 @@ int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_input
     if (form != MPCB_COUPLED_JERK && form != MPCB_COUPLED_VEL && form != MPCB_COUPLED_REF)
         return fail(MPCB_E_ARG, "handle was not created for a coupled formulation");
     if (B == 0) return 0;
-    if (!in->x0 || !in->y0 || !in->speed || !in->feet_x || !in->feet_y || !in->swing0)
-        return fail(MPCB_E_ARG, "missing coupled input array");
+    if (!in->x0 || !in->y0 || !in->speed) return fail(MPCB_E_ARG, "missing coupled input array");
+    if (!in->rows_pqr && (!in->feet_x || !in->feet_y || !in->swing0))
+        return fail(MPCB_E_ARG, "feet_x, feet_y and swing0 are required unless rows_pqr is given");
+    if (in->rows_pqr && form == MPCB_COUPLED_REF && !in->zref_phase)
+        return fail(MPCB_E_ARG, "COUPLED_REF with rows_pqr needs zref_phase");
     if ((out->active_idx || out->multipliers) && out->active_stride <= 0)
         return fail(MPCB_E_ARG, "active_stride must be positive");
     DeviceGuard guard(h->params.device);
@@ -307,6 +311,8 @@ int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_input
     di.feet_y = in->feet_y;
     di.swing0 = in->swing0;
     di.com0 = in->com0;
+    di.rows_pqr = in->rows_pqr;
+    di.zref_phase = in->zref_phase;
     return solve_two_stage(h, di, *out, B, (hipStream_t)stream);
 }
 
@@ -401,6 +407,23 @@ int mpcb_solve_unconstrained_device(mpcb_handle h, int32_t B, const double *x0, 
     return 0;
 }
 
+int mpcb_solve_unconstrained(mpcb_handle h, int32_t B, const double *x0, const double *zmp_ref,
+                             const mpcb_outputs *out) {
+    if (!h || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
+    DeviceGuard guard(h->params.device);
+    Staging st;
+    const double *dx0, *dz;
+    int rc;
+    const size_t b = (size_t)B, N = (size_t)h->hs.N;
+    if ((rc = st.in(x0, b * 3, &dx0)) || (rc = st.in(zmp_ref, b * N, &dz))) return rc;
+    mpcb_outputs dout;
+    if ((rc = stage_outputs(st, *out, dout, b, N))) return rc;
+    if ((rc = mpcb_solve_unconstrained_device(h, B, dx0, dz, &dout, nullptr))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = fetch_outputs(*out, dout, b, N))) return rc;
+    return 0;
+}
+
 int mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, const mpcb_outputs *out) {
     if (!h || !in || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
     DeviceGuard guard(h->params.device);
@@ -412,7 +435,9 @@ int mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, 
     if ((rc = st.in(in->x0, b * 3, &di.x0)) || (rc = st.in(in->y0, b * 3, &di.y0)) ||
         (rc = st.in(in->speed, b * 2, &di.speed)) || (rc = st.in(in->feet_x, b * 4, &di.feet_x)) ||
         (rc = st.in(in->feet_y, b * 4, &di.feet_y)) || (rc = st.in(in->swing0, b, &di.swing0)) ||
-        (rc = st.in(in->com0, b * 2, &di.com0)))
+        (rc = st.in(in->com0, b * 2, &di.com0)) ||
+        (rc = st.in(in->rows_pqr, b * (size_t)h->hs.m * 3, &di.rows_pqr)) ||
+        (rc = st.in(in->zref_phase, b * (size_t)h->hs.nphase * 2, &di.zref_phase)))
         return rc;
     mpcb_outputs dout;
     if ((rc = stage_outputs(st, *out, dout, b, N))) return rc;

@@ -107,8 +107,13 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                 wy[3] = in.speed[(size_t)inst * 2 + 1];
             }
         }
+        const double *rows = (POLY && in.rows_pqr) ? in.rows_pqr + (size_t)inst * m * 3 : nullptr;
         if constexpr (POLY) {
-            for (int phb = 0; phb < sd.nphase; phb += T) polygon_phase(sd, in, inst, wx[3], wy[3], phb + tid, tab, cref);
+            if (!rows)
+                for (int phb = 0; phb < sd.nphase; phb += T)
+                    polygon_phase(sd, in, inst, wx[3], wy[3], phb + tid, tab, cref);
+            if (in.zref_phase)
+                for (int i = tid; i < 2 * sd.nphase; i += T) cref[i] = in.zref_phase[(size_t)inst * 2 * sd.nphase + i];
         } else {
             for (int k = tid; k < N; k += T) {
                 lo[k] = in.zmin[(size_t)inst * N + k];
@@ -121,15 +126,15 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             else return i < N ? i : i - N;
         };
         auto rowP = [&](int i, int k) -> double {
-            if constexpr (POLY) return tab[(sd.knot_phase[k] * 4 + ws.row_slot[i]) * 3];
+            if constexpr (POLY) return rows ? rows[i * 3] : tab[(sd.knot_phase[k] * 4 + ws.row_slot[i]) * 3];
             else return i < N ? 1.0 : -1.0;
         };
         auto rowQ = [&](int i, int k) -> double {
-            if constexpr (POLY) return tab[(sd.knot_phase[k] * 4 + ws.row_slot[i]) * 3 + 1];
+            if constexpr (POLY) return rows ? rows[i * 3 + 1] : tab[(sd.knot_phase[k] * 4 + ws.row_slot[i]) * 3 + 1];
             else return 0.0;
         };
         auto rowR = [&](int i, int k) -> double {
-            if constexpr (POLY) return tab[(sd.knot_phase[k] * 4 + ws.row_slot[i]) * 3 + 2];
+            if constexpr (POLY) return rows ? rows[i * 3 + 2] : tab[(sd.knot_phase[k] * 4 + ws.row_slot[i]) * 3 + 2];
             else return i < N ? -lo[k] : hi[k];
         };
         // s_i = n_i' x + ci0_i through the ZMP: zx = Zx x0 + Zu x  (never forms CI)

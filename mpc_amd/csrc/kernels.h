@@ -34,6 +34,8 @@ struct DevIn {
     const double *x0, *y0, *speed, *feet_x, *feet_y, *com0;
     const int *swing0;
     const double *zmin, *zmax;        // BOX_1D
+    const double *rows_pqr;           // optional [B][m][3]: caller-built polygon rows
+    const double *zref_phase;         // optional [B][nphase][2]: ZMP reference per phase
 };
 
 // Hand-over from the wave-per-QP kernel to the dense kernel, and the dense kernel's

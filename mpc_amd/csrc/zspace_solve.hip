@@ -139,7 +139,9 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
     } while (0)
 #endif
 
-template <int NPL, bool POLY>
+// ROWS: polygon rows come from the caller (in.rows_pqr, the (p, q, r) of every row of the
+// A, b that computeSteps returned, possibly edited) instead of being built from the feet.
+template <int NPL, bool POLY, bool ROWS>
 __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
                                                       int *unresolved_list, int *unresolved_count) {
     constexpr int ES = POLY ? 4 : 2;
@@ -198,8 +200,11 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
     }
     if constexpr (POLY) {
         // computeSteps + buildPolygonMatrix: lane l builds the polygon of phase l
-        for (int pbase = 0; pbase < sd.nphase; pbase += 64)
-            polygon_phase(sd, in, inst, wx[3], wy[3], pbase + lane, tab, cref);
+        if constexpr (!ROWS)
+            for (int pbase = 0; pbase < sd.nphase; pbase += 64)
+                polygon_phase(sd, in, inst, wx[3], wy[3], pbase + lane, tab, cref);
+        if (in.zref_phase)
+            for (int i = lane; i < 2 * sd.nphase; i += 64) cref[i] = in.zref_phase[(size_t)inst * 2 * sd.nphase + i];
 #pragma unroll
         for (int c = 0; c < NPL; c++) {
             ph[c] = sd.knot_phase[kc[c]];
@@ -257,16 +262,26 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
         wsync();
     };
 
+    // caller-built rows: row0[c] + e may run past the knot's last row for a slot that does
+    // not exist; clamp so the (masked) read stays inside the instance's rows
+    const double *rows = ROWS ? in.rows_pqr + (size_t)inst * sd.m * 3 : nullptr;
+    auto rowIdx = [&](int c, int e) -> int {
+        const int r = row0[c] + e;
+        return r < sd.m ? r : sd.m - 1;
+    };
     auto slotP = [&](int c, int e) -> double {
-        if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3];
+        if constexpr (ROWS) return rows[rowIdx(c, e) * 3];
+        else if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3];
         else return e == 0 ? 1.0 : -1.0;
     };
     auto slotQ = [&](int c, int e) -> double {
-        if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3 + 1];
+        if constexpr (ROWS) return rows[rowIdx(c, e) * 3 + 1];
+        else if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3 + 1];
         else return 0.0;
     };
     auto slotR = [&](int c, int e) -> double {
-        if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3 + 2];
+        if constexpr (ROWS) return rows[rowIdx(c, e) * 3 + 2];
+        else if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3 + 2];
         else return e == 0 ? -lo[c] : hi[c];
     };
     auto slotRow = [&](int c, int e) -> int {
@@ -423,7 +438,10 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                 break;
             }
             const int kip = ipKS >> 2, eip = ipKS & 3;
-            if constexpr (POLY) {
+            if constexpr (ROWS) {
+                pip = rows[ipRow * 3];
+                qip = rows[ipRow * 3 + 1];
+            } else if constexpr (POLY) {
                 const int php = sd.knot_phase[kip];
                 pip = tab[(php * 4 + eip) * 3];
                 qip = tab[(php * 4 + eip) * 3 + 1];
@@ -700,12 +718,12 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
 #endif
 }
 
-template <int NPL, bool POLY>
+template <int NPL, bool POLY, bool ROWS>
 hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
                       const DenseWs &ws, hipStream_t stream) {
     const size_t per_wave = sizeof(WaveState) + (POLY ? (size_t)sd.nphase * 14 * 8 : 0);
     const size_t shmem = 4 * per_wave;
-    auto kfn = zspace_kernel<NPL, POLY>;
+    auto kfn = zspace_kernel<NPL, POLY, ROWS>;
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -723,14 +741,19 @@ hipError_t launch_zspace(const DevSetup &sd, const DevIn &in, const mpcb_outputs
     if (B <= 0) return hipSuccess;
     const bool poly = sd.form != MPCB_BOX_1D;
     const int npl = (sd.N + 63) / 64;
-    if (poly) {
-        if (npl <= 2) return launch_one<2, true>(sd, in, out, B, ws, stream);
-        if (npl <= 4) return launch_one<4, true>(sd, in, out, B, ws, stream);
-        return launch_one<8, true>(sd, in, out, B, ws, stream);
+    if (poly && in.rows_pqr) {
+        if (npl <= 2) return launch_one<2, true, true>(sd, in, out, B, ws, stream);
+        if (npl <= 4) return launch_one<4, true, true>(sd, in, out, B, ws, stream);
+        return launch_one<8, true, true>(sd, in, out, B, ws, stream);
     }
-    if (npl <= 2) return launch_one<2, false>(sd, in, out, B, ws, stream);
-    if (npl <= 4) return launch_one<4, false>(sd, in, out, B, ws, stream);
-    return launch_one<8, false>(sd, in, out, B, ws, stream);
+    if (poly) {
+        if (npl <= 2) return launch_one<2, true, false>(sd, in, out, B, ws, stream);
+        if (npl <= 4) return launch_one<4, true, false>(sd, in, out, B, ws, stream);
+        return launch_one<8, true, false>(sd, in, out, B, ws, stream);
+    }
+    if (npl <= 2) return launch_one<2, false, false>(sd, in, out, B, ws, stream);
+    if (npl <= 4) return launch_one<4, false, false>(sd, in, out, B, ws, stream);
+    return launch_one<8, false, false>(sd, in, out, B, ws, stream);
 }
 
 } // namespace mpcb

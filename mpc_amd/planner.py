@@ -20,10 +20,10 @@ OK, INFEASIBLE, ITER_CAP = 0, 1, 2
 MODE_AUTO, MODE_DENSE = 0, 1
 
 # every symbol include/mpc_amd.h declares
-EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constraints",
+EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constraints", "mpcb_num_phases",
            "mpcb_solve_coupled_device", "mpcb_solve_coupled", "mpcb_solve_box_device",
            "mpcb_solve_box", "mpcb_get_matrix", "mpcb_replan_sweep_device",
-           "mpcb_solve_unconstrained_device")
+           "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained")
 
 
 class Params(C.Structure):
@@ -37,7 +37,7 @@ class Params(C.Structure):
 
 class CoupledInputs(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in
-                ("x0", "y0", "speed", "feet_x", "feet_y", "swing0", "com0")]
+                ("x0", "y0", "speed", "feet_x", "feet_y", "swing0", "com0", "rows_pqr", "zref_phase")]
 
 
 class ReplanState(C.Structure):
@@ -192,15 +192,21 @@ class BatchedPlanner:
         return out
 
     # -- solves ----------------------------------------------------------------
-    def prepare_coupled(self, x0, y0, speed, feet_x, feet_y, swing0, com0=None):
-        """Uploads one batch of coupled inputs; returns an opaque (B, struct, keepalive)."""
+    def prepare_coupled(self, x0, y0, speed, feet_x=None, feet_y=None, swing0=None, com0=None,
+                        rows_pqr=None, zref_phase=None):
+        """Uploads one batch of coupled inputs; returns an opaque (B, struct, keepalive).
+        rows_pqr [B, m, 3] replaces the footstep inputs by caller-built polygon rows;
+        zref_phase [B, 2*steps+1, 2] overrides the centroid ZMP reference (COUPLED_REF)."""
         f64, i32 = self._torch.float64, self._torch.int32
         ts = dict(x0=self._dev(x0, f64), y0=self._dev(y0, f64), speed=self._dev(speed, f64),
                   feet_x=self._dev(feet_x, f64), feet_y=self._dev(feet_y, f64),
-                  swing0=self._dev(swing0, i32), com0=self._dev(com0, f64))
+                  swing0=self._dev(swing0, i32), com0=self._dev(com0, f64),
+                  rows_pqr=self._dev(rows_pqr, f64), zref_phase=self._dev(zref_phase, f64))
         B = ts["x0"].shape[0]
+        nph = 2 * self.params.number_of_steps + 1
         shapes = dict(x0=(B, 3), y0=(B, 3), speed=(B, 2), feet_x=(B, 4), feet_y=(B, 4),
-                      swing0=(B,), com0=(B, 2))
+                      swing0=(B,), com0=(B, 2), rows_pqr=(B, self.num_constraints, 3),
+                      zref_phase=(B, nph, 2))
         ci = CoupledInputs()
         for k, t in ts.items():
             if t is None:
@@ -219,11 +225,12 @@ class BatchedPlanner:
                                                         self._stream(stream)))
         return res
 
-    def solve_coupled(self, x0, y0, speed, feet_x, feet_y, swing0, com0=None,
-                      outputs=DEFAULT_OUTPUTS, stream=None):
+    def solve_coupled(self, x0, y0, speed, feet_x=None, feet_y=None, swing0=None, com0=None,
+                      rows_pqr=None, zref_phase=None, outputs=DEFAULT_OUTPUTS, stream=None):
         """computeSteps + solveQPConstraintCoupled + trajectory read-out for B instances.
         Returns a dict of device tensors (asynchronous on `stream`)."""
-        prepared = self.prepare_coupled(x0, y0, speed, feet_x, feet_y, swing0, com0)
+        prepared = self.prepare_coupled(x0, y0, speed, feet_x, feet_y, swing0, com0, rows_pqr,
+                                        zref_phase)
         return self.solve_coupled_prepared(prepared, outputs=outputs, stream=stream)
 
     def prepare_box(self, x0, zmin, zmax):

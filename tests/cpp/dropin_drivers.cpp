@@ -1,0 +1,165 @@
+// Non-interactive equivalents of the reference's drivers, written against the
+// MPCPlanner-shaped C++ interface (include/mpc_amd_planner.hpp):
+//   coupled   tests/constrainedQP_coupled/testPlannerXYconstraintCoupled.cpp   (defaults)
+//   decoupled tests/constrainedQP_decoupled/testPlannerXYconstraintDecoupled.cpp (defaults)
+//   qp        tests/unconstrainedQP/testPlanner.cpp                              (defaults)
+// Each writes the same "time value" text files into $HOME through saveTraj and prints a
+// few values as key=value lines for the test that runs it.
+#include <cstdio>
+#include <cstring>
+
+#include "mpc_amd_planner.hpp"
+
+using namespace mpc_amd;
+
+static int coupled() {
+    int horizon_size = 200, number_of_steps = 20;
+    double height = 0.5, Ts = 0.1, weight_R = 0.01, weight_Q = 1, weight_Qs = 100;
+    VectorXd jerk_x, jerk_y, zmp_x, zmp_y, com_x, com_y, com_xd, com_yd, viol, centroidX, centroidY;
+    Vector3d initial_state_x = {0.0, 0.0, 0.0}, initial_state_y = {0.0, -0.0, 0.0};
+    MatrixXd A;
+    VectorXd b;
+    Vector2d userSpeed = {0.15, 0.0};
+    MPCPlanner myPlanner(horizon_size, Ts, 9.81);
+    LegDataMap<MPCPlanner::footState> feetStates, footHolds;
+    LegDataMap<double> initial_feet_x, initial_feet_y;
+    initial_feet_x[LF] = initial_state_x[0] + 0.1;
+    initial_feet_x[RF] = initial_state_x[0] + 0.2;
+    initial_feet_x[LH] = initial_feet_x[LF] - 0.5;
+    initial_feet_x[RH] = initial_feet_x[RF] - 0.5;
+    initial_feet_y[LF] = initial_state_y[0] + 1.0;
+    initial_feet_y[RF] = initial_state_y[0] - 1.0;
+    initial_feet_y[LH] = initial_state_y[0] + 1.0;
+    initial_feet_y[RH] = initial_state_y[0] - 1.0;
+    myPlanner.computeSteps(userSpeed, initial_feet_x, initial_feet_y, number_of_steps, horizon_size, feetStates,
+                           footHolds, A, b, myPlanner, LF);
+    myPlanner.computeCentroid(feetStates, centroidX, centroidY);
+    myPlanner.setWeights(weight_R, weight_Q, weight_Qs);
+    myPlanner.solveQPConstraintCoupledRef(height, initial_state_x, initial_state_y, centroidX, centroidY, A, b,
+                                          userSpeed, jerk_x, jerk_y);
+    viol = myPlanner.getConstraintViolation(feetStates);
+    myPlanner.computeZMPtrajectory(initial_state_x, jerk_x, zmp_x);
+    myPlanner.computeZMPtrajectory(initial_state_y, jerk_y, zmp_y);
+    myPlanner.computeCOMtrajectory(initial_state_x, jerk_x, com_x);
+    myPlanner.computeCOMtrajectory(initial_state_y, jerk_y, com_y);
+    myPlanner.computeCOMtrajectory(initial_state_x, jerk_x, com_xd, MPCPlanner::VELOCITY);
+    myPlanner.computeCOMtrajectory(initial_state_y, jerk_y, com_yd, MPCPlanner::VELOCITY);
+    myPlanner.saveTraj("jerk_x.txt", jerk_x);
+    myPlanner.saveTraj("jerk_y.txt", jerk_y);
+    myPlanner.saveTraj("zmp_x.txt", zmp_x);
+    myPlanner.saveTraj("zmp_y.txt", zmp_y);
+    myPlanner.saveTraj("com_x.txt", com_x);
+    myPlanner.saveTraj("com_y.txt", com_y);
+    myPlanner.saveTraj("com_xd.txt", com_xd);
+    myPlanner.saveTraj("com_yd.txt", com_yd);
+    myPlanner.saveTraj("viol.txt", viol);
+    myPlanner.saveTraj("centroidX.txt", centroidX);
+    myPlanner.saveTraj("centroidY.txt", centroidY);
+    myPlanner.saveTraj("footPosLF.txt", feetStates[LF].x, feetStates[LF].y);
+    myPlanner.saveTraj("footHoldsLF.txt", footHolds[LF].x, footHolds[LF].y);
+    myPlanner.saveTraj("swingLF.txt", feetStates[LF].swing);
+    double mn = viol[0];
+    for (double v : viol) mn = v < mn ? v : mn;
+    std::printf("jerk_x0=%.9g\njerk_x1=%.9g\njerk_x2=%.9g\ncom_x199=%.9g\nmin_margin=%.9g\nn_active=%d\ncost=%.12g\n",
+                jerk_x[0], jerk_x[1], jerk_x[2], com_x[199], mn, (int)myPlanner.lastActiveSet().size(),
+                myPlanner.lastCost());
+    // the velocity formulation on the same polygons (constraints bind)
+    myPlanner.solveQPConstraintCoupled(height, initial_state_x, initial_state_y, A, b, userSpeed, jerk_x, jerk_y);
+    std::printf("vel_n_active=%d\nvel_cost=%.12g\nvel_jerk_x0=%.12g\n", (int)myPlanner.lastActiveSet().size(),
+                myPlanner.lastCost(), jerk_x[0]);
+    return 0;
+}
+
+static int decoupled() {
+    int horizon_size = 100, number_of_steps = 10;
+    double distance = 3.0, height = 0.5, lateral_bound = 0.2, Ts = 0.1, weight_R = 1, weight_Q = 1;
+    VectorXd jerk_x, jerk_y, zmp_x, zmp_y, com_x, com_y;
+    Vector3d initial_state_x = {0.0, 0.0, 0.0}, initial_state_y = {0.0, -0.0, 0.0};
+    MPCPlanner::BoxLimits zmpLimX, zmpLimY;
+    double distance_per_step = distance / number_of_steps;
+    int step_knots = horizon_size / number_of_steps;
+    MPCPlanner myPlanner(horizon_size, Ts, 9.81);
+    myPlanner.setWeights(weight_R, weight_Q);
+    zmpLimX.resize(horizon_size);
+    zmpLimY.resize(horizon_size);
+    int start = 0, phase = step_knots / 2;
+    double low = 0.0, overlap = 0.1;
+    bool goleft = true;
+    auto fill = [](VectorXd &v, int from, int len, double val) {
+        for (int k = from; k < from + len; k++) v[k] = val;
+    };
+    for (int i = 0; i < number_of_steps - 1; i++) {
+        fill(zmpLimX.max, start, phase, low + distance_per_step * (0.5 + overlap));
+        fill(zmpLimX.min, start, phase, low - distance_per_step * overlap);
+        fill(zmpLimY.max, start, phase, 1.0);
+        fill(zmpLimY.min, start, phase, -1.0);
+        start += phase;
+        low += distance_per_step / 2;
+        fill(zmpLimX.max, start, phase, low + distance_per_step / 2);
+        fill(zmpLimX.min, start, phase, low);
+        if (goleft) {
+            fill(zmpLimY.max, start, phase, 1.0);
+            fill(zmpLimY.min, start, phase, lateral_bound);
+        } else {
+            fill(zmpLimY.max, start, phase, -lateral_bound);
+            fill(zmpLimY.min, start, phase, -1.0);
+        }
+        goleft = !goleft;
+        start += phase;
+        low += distance_per_step / 2;
+    }
+    int missing = horizon_size - start;
+    fill(zmpLimX.max, start, missing, distance);
+    fill(zmpLimX.min, start, missing, low - distance_per_step * overlap);
+    fill(zmpLimY.max, start, missing, 1.0);
+    fill(zmpLimY.min, start, missing, -1.0);
+    myPlanner.solveQPconstraint(height, initial_state_x, zmpLimX, jerk_x);
+    const int nx = (int)myPlanner.lastActiveSet().size();
+    myPlanner.solveQPconstraint(height, initial_state_y, zmpLimY, jerk_y);
+    const int ny = (int)myPlanner.lastActiveSet().size();
+    myPlanner.computeZMPtrajectory(initial_state_x, jerk_x, zmp_x);
+    myPlanner.computeZMPtrajectory(initial_state_y, jerk_y, zmp_y);
+    myPlanner.computeCOMtrajectory(initial_state_x, jerk_x, com_x);
+    myPlanner.computeCOMtrajectory(initial_state_y, jerk_y, com_y);
+    myPlanner.saveTraj("jerk_x.txt", jerk_x);
+    myPlanner.saveTraj("jerk_y.txt", jerk_y);
+    myPlanner.saveTraj("zmp_x.txt", zmp_x);
+    myPlanner.saveTraj("zmp_y.txt", zmp_y);
+    myPlanner.saveTraj("min_y.txt", zmpLimY.min);
+    myPlanner.saveTraj("max_y.txt", zmpLimY.max);
+    std::printf("jerk_y0=%.9g\njerk_y1=%.9g\njerk_y2=%.9g\nx_active=%d\ny_active=%d\n", jerk_y[0], jerk_y[1],
+                jerk_y[2], nx, ny);
+    return 0;
+}
+
+static int qp() {
+    int horizon_size = 100;
+    double height = 0.5, Ts = 0.1, weight_R = 1e-06, weight_Q = 1;
+    VectorXd jerk, zmp_x, com_x, zmpRef(horizon_size);
+    Vector3d initial_state = {0.2, -0.1, 0.0};
+    MPCPlanner myPlanner(horizon_size, Ts, 9.81);
+    myPlanner.setWeights(weight_R, weight_Q);
+    for (int i = 0; i < horizon_size; i++) zmpRef[i] = 0.2 * i / (horizon_size - 1); // setLinSpaced(N, 0, 0.2)
+    myPlanner.solveQP(height, initial_state, zmpRef, jerk);
+    myPlanner.computeZMPtrajectory(initial_state, jerk, zmp_x);
+    myPlanner.computeCOMtrajectory(initial_state, jerk, com_x, MPCPlanner::POSITION);
+    myPlanner.saveTraj("zmpRef.txt", zmpRef);
+    myPlanner.saveTraj("jerk.txt", jerk);
+    myPlanner.saveTraj("zmp.txt", zmp_x);
+    myPlanner.saveTraj("com.txt", com_x);
+    std::printf("zmp50=%.9g\nzmp99=%.9g\ncom99=%.9g\n", zmp_x[50], zmp_x[99], com_x[99]);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    try {
+        if (argc > 1 && !std::strcmp(argv[1], "coupled")) return coupled();
+        if (argc > 1 && !std::strcmp(argv[1], "decoupled")) return decoupled();
+        if (argc > 1 && !std::strcmp(argv[1], "qp")) return qp();
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 2;
+    }
+    std::fprintf(stderr, "usage: %s coupled|decoupled|qp\n", argv[0]);
+    return 1;
+}

