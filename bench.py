@@ -12,7 +12,12 @@ Workloads (--workload):
                variables, m=700 polygon rows, velocity formulation R=0.01 Q=1 (constraints
                bind).  At 8 GPUs this is the 65,536-instance batch.
   coupled_jerk same shape, jerk-only formulation.
+  coupled_ref  same shape, ZMP-reference formulation with the driver's weights R=0.01 Q=1
+               Qs=100 (no constraint binds: shape fidelity).
   decoupled    4,096 X/Y pairs of box-constrained 1-D QPs per GPU, N=100, m=200 per axis.
+  replanning   16,384 rollouts per GPU x 8 sequentially dependent replans (131,072 solves
+               per step), velocity formulation with Gaussian weights (window 10), CoM step
+               correction, per-rollout Y-jerk disturbance.
 
 Instances are independent, so rank r solves instances [r*B, (r+1)*B) of one global batch
 and nothing is exchanged during a step (weak scaling).
@@ -53,10 +58,11 @@ class CoupledWorkload:
         self.N, self.steps_per_plan = 200, 20
         self.B = B
         self.form = form
-        self.name = "coupled_vel" if form == P.COUPLED_VEL else "coupled_jerk"
+        self.name = {P.COUPLED_VEL: "coupled_vel", P.COUPLED_JERK: "coupled_jerk",
+                     P.COUPLED_REF: "coupled_ref"}[form]
         self.inputs = batches.coupled_batch(B, first=first)
         self.pl = P.BatchedPlanner(self.N, formulation=form, weight_R=0.01, weight_Q=1.0,
-                                   number_of_steps=self.steps_per_plan, device=dev)
+                                   weight_Qs=100.0, number_of_steps=self.steps_per_plan, device=dev)
         self.prepared = self.pl.prepare_coupled(**self.inputs)
         self.out = self.pl._alloc_outputs(B, P.ALL_OUTPUTS)
         self.units = B
@@ -81,7 +87,8 @@ class CoupledWorkload:
     def cpu_baseline(self, threads, sample):
         from oracle import oracle as O
         p = O.params(self.N, R=0.01, Q=1.0, Qs=100.0, height=0.5, dense=1, iter_cap=0)
-        oform = O.COUPLED_VEL if self.form == P.COUPLED_VEL else O.COUPLED_JERK
+        oform = {P.COUPLED_VEL: O.COUPLED_VEL, P.COUPLED_JERK: O.COUPLED_JERK,
+                 P.COUPLED_REF: O.COUPLED_REF}[self.form]
         i = self.inputs
         t = time.perf_counter()
         ref = O.coupled_batch(p, oform, self.steps_per_plan, 1000, i["x0"][:sample], i["y0"][:sample],
@@ -89,6 +96,59 @@ class CoupledWorkload:
                               i["swing0"][:sample], nthreads=threads)
         dt = time.perf_counter() - t
         return sample / dt, ref
+
+
+class ReplanningWorkload:
+    unit = "solves/s"
+    STAGES = 8
+
+    def __init__(self, B, first, dev):
+        self.N, self.steps_per_plan = 200, 20
+        self.B = B
+        self.name = "replanning"
+        self.inputs = batches.coupled_batch(B, first=first)
+        self.dist = batches.replanning_disturbance(B, first=first)
+        self.hip = batches.NOMINAL_HIP_OFFSETS
+        self.pl = P.BatchedPlanner(self.N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0,
+                                   replanning_window=self.N // self.steps_per_plan,
+                                   number_of_steps=self.steps_per_plan, hip_offsets=self.hip, device=dev)
+        self.prepared = self.pl.prepare_replanning(disturbance=self.dist, **self.inputs)
+        self.pristine = {k: self.prepared[2][k].clone() for k in ("x0", "y0", "feet_x", "feet_y", "swing0")}
+        self.out = self.pl._alloc_outputs(B, P.ALL_OUTPUTS)
+        self.units = B * self.STAGES
+        self.launches = self.STAGES
+        self.alg_bytes = self.STAGES * B * (8 * (25 + 6 * self.N + 2) + 4 * (self.pl.active_stride + 4))
+        self.stage = None
+
+    def step(self):
+        for k, t in self.pristine.items():  # every sweep starts from the same initial state
+            self.prepared[2][k].copy_(t)
+        _, self.stage, _ = self.pl.replan_sweep(self.prepared, self.STAGES, out=self.out)
+
+    def results(self):
+        return self.out[0]
+
+    def alg_flops(self):
+        # the last stage's count stands in for every stage (stages are statistically alike)
+        return float(self.out[0]["alg_flops"].sum().item()) * self.STAGES
+
+    def describe(self):
+        return {"workload": self.name, "rollouts_per_gpu": self.B, "stages": self.STAGES, "horizon": self.N,
+                "number_of_steps": 20, "replanning_window": 10, "variables": 400,
+                "constraints": self.pl.num_constraints, "weights": {"R": 0.01, "Q": 1.0},
+                "com_step_correction": True, "seed": batches.SEED}
+
+    def cpu_baseline(self, threads, sample):
+        from oracle import oracle as O
+        p = O.params(self.N, R=0.01, Q=1.0, height=0.5, dense=1, iter_cap=0)
+        i = self.inputs
+        sample = max(threads, sample // self.STAGES)
+        t = time.perf_counter()
+        ref = O.replanning_batch(p, self.steps_per_plan, self.STAGES, i["x0"][:sample], i["y0"][:sample],
+                                 i["speed"][:sample], i["feet_x"][:sample], i["feet_y"][:sample],
+                                 i["swing0"][:sample], self.dist[:sample], hip=self.hip, nthreads=threads)
+        dt = time.perf_counter() - t
+        return sample * self.STAGES / dt, ref
 
 
 class DecoupledWorkload:
@@ -140,7 +200,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="coupled_vel",
-                    choices=("coupled_vel", "coupled_jerk", "decoupled"))
+                    choices=("coupled_vel", "coupled_jerk", "coupled_ref", "decoupled", "replanning"))
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (0 = workload default)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="instances timed on the host cores (0 disables, -1 = default)")
@@ -161,9 +221,13 @@ def main():
     if args.workload == "decoupled":
         B = args.batch or 4096
         wl = DecoupledWorkload(B, rank * B, dev)
+    elif args.workload == "replanning":
+        B = args.batch or 16384
+        wl = ReplanningWorkload(B, rank * B, dev)
     else:
         B = args.batch or 8192
-        form = P.COUPLED_VEL if args.workload == "coupled_vel" else P.COUPLED_JERK
+        form = {"coupled_vel": P.COUPLED_VEL, "coupled_jerk": P.COUPLED_JERK,
+                "coupled_ref": P.COUPLED_REF}[args.workload]
         wl = CoupledWorkload(form, B, rank * B, dev)
 
     def barrier():
@@ -243,7 +307,7 @@ def main():
         }
         sample = args.cpu_sample
         if sample < 0:
-            sample = 192 if args.workload != "decoupled" else 2048
+            sample = 2048 if args.workload == "decoupled" else 192
         if world == 1 and sample > 0:
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
             sample = min(sample, wl.B)
