@@ -27,9 +27,22 @@ namespace {
 
 constexpr int T = 256;
 
+// Diagnostic build only (-DMPCB_STAMPS): cycles per section into sd.dbg[inst*10 + section].
+#ifdef MPCB_STAMPS
+#define DSTAMP(i)                                          \
+    do {                                                   \
+        const long long t_ = __builtin_amdgcn_s_memtime(); \
+        stamp_acc[i] += t_ - stamp_t;                      \
+        stamp_t = t_;                                      \
+    } while (0)
+#else
+#define DSTAMP(i) \
+    do {          \
+    } while (0)
+#endif
+
 __device__ __forceinline__ double block_sum(double v, double *red, int tid) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = wave_sum(v);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
@@ -38,15 +51,8 @@ __device__ __forceinline__ double block_sum(double v, double *red, int tid) {
 
 // minimum of (val, key), smaller key wins ties; result identical in every thread
 __device__ __forceinline__ void block_argmin(double &val, int &key, double *red, int *redk, int tid) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(val, o, 64);
-        const int ok = __shfl_xor(key, o, 64);
-        if (ov < val || (ov == val && ok < key)) {
-            val = ov;
-            key = ok;
-        }
-    }
+    int aux = 0;
+    wave_argmin(val, key, aux);
     __syncthreads();
     if ((tid & 63) == 0) {
         red[tid >> 6] = val;
@@ -63,7 +69,9 @@ __device__ __forceinline__ void block_argmin(double &val, int &key, double *red,
         }
 }
 
-template <bool POLY>
+// LDSJ: J (n x n) and R (packed, one sub-diagonal) live in the workgroup's LDS instead of
+// its HBM workspace slot -- possible up to n ~ 105, e.g. the N = 100 box problems.
+template <bool POLY, bool LDSJ>
 __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_outputs out, DenseWs ws) {
     extern __shared__ double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,20 +83,40 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
     double *s = suf + (n + 1);
     double *zx = s + m, *zy = zx + N;
     double *lo = zy + N, *hi = lo + N;                                   // BOX limits
-    double *tab = hi + N;                                                // POLY: [phase][edge][p,q,r]
+    double *zc = hi + N;                                                 // Toeplitz column of Zu
+    double *tab = zc + N;                                                // POLY: [phase][edge][p,q,r]
     double *cref = tab + (POLY ? sd.nphase * 12 : 0);                    // POLY: [phase][x,y]
     double *red = cref + (POLY ? sd.nphase * 2 : 0);
     int *redk = reinterpret_cast<int *>(red + 4);
     int *A = redk + 4, *A_old = A + (n + 1), *iai = A_old + (n + 1);
     int *iaexcl = iai + m;
+    // 8-byte aligned start of the LDS-resident matrices
+    double *lds_mats = reinterpret_cast<double *>((reinterpret_cast<size_t>(iaexcl + m) + 7) & ~(size_t)7);
     __shared__ int sh_i[4];
-    __shared__ double sh_d[4];
+    // leading dimension of J: odd in LDS so that one thread per column walks conflict-free
+    const int ldj = LDSJ ? (n | 1) : n;
+    // R(i, k), i <= k + 1: full column-major in HBM; in LDS column k keeps k + 2 entries
+    auto ridx = [&](int i, int k) -> size_t {
+        if constexpr (LDSJ) return (size_t)k * (k + 3) / 2 + i;
+        else return (size_t)k * n + i;
+    };
 
+    for (int k = tid; k < N; k += T) zc[k] = ws.zu_col[k];
     const int count = *ws.count;
     for (int entry = blockIdx.x; entry < count; entry += gridDim.x) {
         const int inst = ws.list[entry];
-        double *J = ws.J + (size_t)blockIdx.x * n * n;   // column-major n x n
-        double *R = ws.R + (size_t)blockIdx.x * n * n;   // column-major, upper triangle used
+#ifdef MPCB_STAMPS
+        long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
+        double *J, *R; // J column-major n x ldj; R upper triangular plus one sub-diagonal
+        if constexpr (LDSJ) {
+            J = lds_mats;
+            R = lds_mats + (size_t)n * ldj;
+        } else {
+            J = ws.J + (size_t)blockIdx.x * n * n;
+            R = ws.R + (size_t)blockIdx.x * n * n;
+        }
         __syncthreads();
 
         // ---- inputs, constraint rows ---------------------------------------
@@ -143,8 +171,9 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                 const double *zr = ws.zx + (size_t)k * 3;
                 double ax = zr[0] * wx[0] + zr[1] * wx[1] + zr[2] * wx[2];
                 double ay = zr[0] * wy[0] + zr[1] * wy[1] + zr[2] * wy[2];
+#pragma unroll 8
                 for (int j = 0; j <= k; j++) {
-                    const double c = ws.zu_col[k - j];
+                    const double c = zc[k - j];
                     ax += c * x[j];
                     if constexpr (POLY) ay += c * x[N + j];
                 }
@@ -168,13 +197,13 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
 
         // ---- preprocessing (eiquadprog.hpp:162-191) -------------------------
         // J = L^-T = blkdiag(J1, J1); x = -G^-1 g0 ; f = 1/2 g0'x
-        for (size_t e = tid; e < (size_t)n * n; e += T) {
-            const int col = (int)(e / n), row = (int)(e % n);
-            double v = 0.0;
-            if (col < N && row < N) v = ws.J1[(size_t)col * N + row];
-            else if (col >= N && row >= N) v = ws.J1[(size_t)(col - N) * N + (row - N)];
-            J[e] = v;
-        }
+        for (int col = 0; col < n; col++)
+            for (int row = tid; row < n; row += T) {
+                double v = 0.0;
+                if (col < N && row < N) v = ws.J1[(size_t)col * N + row];
+                else if (col >= N && row >= N) v = ws.J1[(size_t)(col - N) * N + (row - N)];
+                J[(size_t)col * ldj + row] = v;
+            }
         for (int i = tid; i < n; i += T) {
             const int k = i < N ? i : i - N;
             const double *kx = sd.Kx + (size_t)k * 4;
@@ -222,7 +251,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             }
             // shift A, u and the columns of R
             for (int row = tid; row < iq; row += T)
-                for (int i = qq; i < iq - 1; i++) R[(size_t)i * n + row] = R[(size_t)(i + 1) * n + row];
+                for (int i = (qq > row - 1 ? qq : row - 1); i < iq - 1; i++) R[ridx(row, i)] = R[ridx(row, i + 1)];
             if (tid == 0) {
                 for (int i = qq; i < iq - 1; i++) {
                     A[i] = A[i + 1];
@@ -234,14 +263,72 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                 u[iq] = 0.0;
             }
             __syncthreads();
-            for (int j = tid; j < iq; j += T) R[(size_t)(iq - 1) * n + j] = 0.0;
+            for (int j = tid; j < iq; j += T) R[ridx(j, iq - 1)] = 0.0;
             iq--;
             __syncthreads();
             if (iq == 0) return;
             // rotations of rows (j, j+1) of R: a true sequential chain
+            if constexpr (LDSJ) {
+                // n <= 128: wave 0, lane k (and k+64) owns column k and carries the current
+                // row-j entry in a register; the pivot pair travels by readlane
+                if (wave == 0) {
+                    const int k0 = lane, k1 = lane + 64;
+                    double top0 = (k0 >= qq && k0 < iq) ? R[ridx(qq, k0)] : 0.0;
+                    double top1 = (k1 >= qq && k1 < iq) ? R[ridx(qq, k1)] : 0.0;
+                    for (int j = qq; j < iq; j++) {
+                        const double bot0 = (k0 >= j && k0 < iq) ? R[ridx(j + 1, k0)] : 0.0;
+                        const double bot1 = (k1 >= j && k1 < iq) ? R[ridx(j + 1, k1)] : 0.0;
+                        const double tsel = j >= 64 ? top1 : top0, bsel = j >= 64 ? bot1 : bot0;
+                        const double tj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tsel), j & 63),
+                                                           __builtin_amdgcn_readlane(__double2loint(tsel), j & 63));
+                        const double bj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bsel), j & 63),
+                                                           __builtin_amdgcn_readlane(__double2loint(bsel), j & 63));
+                        const double h = distance(tj, bj);
+                        if (h == 0.0) {
+                            if (lane == 0) {
+                                rc[j] = 1.0;
+                                rs[j] = 0.0;
+                                rx[j] = DINF;
+                            }
+                            if (k0 >= j && k0 < iq) R[ridx(j, k0)] = top0;
+                            if (k1 >= j && k1 < iq) R[ridx(j, k1)] = top1;
+                            top0 = bot0;
+                            top1 = bot1;
+                            continue;
+                        }
+                        double cc = tj / h, ss = bj / h, hd = h;
+                        if (cc < 0.0) {
+                            cc = -cc;
+                            ss = -ss;
+                            hd = -h;
+                        }
+                        const double xny = ss / (1.0 + cc);
+                        if (lane == 0) {
+                            rc[j] = cc;
+                            rs[j] = ss;
+                            rx[j] = xny;
+                        }
+                        if (k0 == j || k1 == j) {
+                            R[ridx(j, j)] = hd;
+                            R[ridx(j + 1, j)] = 0.0;
+                        }
+                        if (k0 > j && k0 < iq) {
+                            const double nv = top0 * cc + bot0 * ss;
+                            R[ridx(j, k0)] = nv;
+                            top0 = xny * (top0 + nv) - bot0;
+                        }
+                        if (k1 > j && k1 < iq) {
+                            const double nv = top1 * cc + bot1 * ss;
+                            R[ridx(j, k1)] = nv;
+                            top1 = xny * (top1 + nv) - bot1;
+                        }
+                    }
+                }
+                __syncthreads();
+            } else {
             for (int j = qq; j < iq; j++) {
                 if (tid == 0) {
-                    double cc = R[(size_t)j * n + j], ss = R[(size_t)j * n + j + 1];
+                    double cc = R[ridx(j, j)], ss = R[ridx(j + 1, j)];
                     const double h = distance(cc, ss);
                     if (h == 0.0) {
                         rc[j] = 1.0;
@@ -250,13 +337,13 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     } else {
                         cc /= h;
                         ss /= h;
-                        R[(size_t)j * n + j + 1] = 0.0;
+                        R[ridx(j + 1, j)] = 0.0;
                         if (cc < 0.0) {
-                            R[(size_t)j * n + j] = -h;
+                            R[ridx(j, j)] = -h;
                             cc = -cc;
                             ss = -ss;
                         } else
-                            R[(size_t)j * n + j] = h;
+                            R[ridx(j, j)] = h;
                         rc[j] = cc;
                         rs[j] = ss;
                         rx[j] = ss / (1.0 + cc);
@@ -266,34 +353,55 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                 if (rx[j] != DINF) {
                     const double cc = rc[j], ss = rs[j], xny = rx[j];
                     for (int k = j + 1 + tid; k < iq; k += T) {
-                        const double t1 = R[(size_t)k * n + j], t2 = R[(size_t)k * n + j + 1];
+                        const double t1 = R[ridx(j, k)], t2 = R[ridx(j + 1, k)];
                         const double nv = t1 * cc + t2 * ss;
-                        R[(size_t)k * n + j] = nv;
-                        R[(size_t)k * n + j + 1] = xny * (t1 + nv) - t2;
+                        R[ridx(j, k)] = nv;
+                        R[ridx(j + 1, k)] = xny * (t1 + nv) - t2;
                     }
                 }
                 __syncthreads();
             }
-            // the same rotations on columns (j, j+1) of J: one thread per row
+            }
+            // the same rotations on columns (j, j+1) of J: one thread per row.  Eight columns
+            // are read before any is written back so the loads overlap (a store to J between
+            // two loads would otherwise serialise them).
             for (int row = tid; row < n; row += T) {
-                double t1 = J[(size_t)qq * n + row];
-                for (int j = qq; j < iq; j++) {
-                    const double t2 = J[(size_t)(j + 1) * n + row];
-                    if (rx[j] == DINF) {
-                        J[(size_t)j * n + row] = t1;
-                        t1 = t2;
-                    } else {
-                        const double nv = t1 * rc[j] + t2 * rs[j];
-                        J[(size_t)j * n + row] = nv;
-                        t1 = rx[j] * (nv + t1) - t2;
+                double t1 = J[(size_t)qq * ldj + row];
+                for (int j0 = qq; j0 < iq; j0 += 8) {
+                    double t2v[8], outv[8], cv[8], sv[8], xv[8];
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; q8++) {
+                        const bool in = j0 + q8 < iq;
+                        t2v[q8] = in ? J[(size_t)(j0 + q8 + 1) * ldj + row] : 0.0;
+                        cv[q8] = in ? rc[j0 + q8] : 1.0;
+                        sv[q8] = in ? rs[j0 + q8] : 0.0;
+                        xv[q8] = in ? rx[j0 + q8] : DINF;
                     }
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; q8++) {
+                        const int j = j0 + q8;
+                        if (j < iq) {
+                            if (xv[q8] == DINF) {
+                                outv[q8] = t1;
+                                t1 = t2v[q8];
+                            } else {
+                                const double nv = t1 * cv[q8] + t2v[q8] * sv[q8];
+                                outv[q8] = nv;
+                                t1 = xv[q8] * (nv + t1) - t2v[q8];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; q8++)
+                        if (j0 + q8 < iq) J[(size_t)(j0 + q8) * ldj + row] = outv[q8];
                 }
-                J[(size_t)iq * n + row] = t1;
+                J[(size_t)iq * ldj + row] = t1;
             }
             __syncthreads();
         };
 
         bool done = false;
+        DSTAMP(0);
         while (!done) { // step 1 (l1)
             iters++;
             if (iters > sd.iter_cap) {
@@ -303,6 +411,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             for (int i = tid; i < iq; i += T) iai[A[i]] = -1;
             for (int i = tid; i < m; i += T) iaexcl[i] = 1;
             eval_s(-1);
+            DSTAMP(1);
             falg += 2.0 * mm * nn;
             double part = 0.0;
             for (int i = tid; i < m; i += T) part += fmin(0.0, s[i]);
@@ -326,6 +435,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                         bi = i;
                     }
                 block_argmin(bv, bi, red, redk, tid);
+                DSTAMP(2);
                 if (bv < ss) {
                     ss = bv;
                     ip = bi;
@@ -339,7 +449,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     const int k = rowK(ip);
                     const double p = rowP(ip, k), q = rowQ(ip, k);
                     for (int j = tid; j < N; j += T) {
-                        const double c = j <= k ? ws.zu_col[k - j] : 0.0;
+                        const double c = j <= k ? zc[k - j] : 0.0;
                         np[j] = p * c;
                         if constexpr (POLY) np[N + j] = q * c;
                     }
@@ -357,32 +467,94 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                         break;
                     }
                     falg += 2.0 * nn * nn + 2.0 * nn * (nn - iq) + (double)iq * iq;
+                    DSTAMP(2);
                     // d = J' np : one wave per column
-                    for (int j = wave; j < n; j += 4) {
-                        const double *col = J + (size_t)j * n;
-                        double acc = 0.0;
-                        for (int k = lane; k < n; k += 64) acc += col[k] * np[k];
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-                        if (lane == 0) d[j] = acc;
+                    if constexpr (LDSJ) {
+                        // one thread per column; the odd leading dimension keeps the lanes on
+                        // different banks
+                        for (int j = tid; j < n; j += T) {
+                            const double *col = J + (size_t)j * ldj;
+                            double acc = 0.0;
+#pragma unroll 8
+                            for (int k = 0; k < n; k++) acc += col[k] * np[k];
+                            d[j] = acc;
+                        }
+                    } else {
+                        for (int j = wave; j < n; j += 4) {
+                            const double *col = J + (size_t)j * ldj;
+                            double acc = 0.0;
+                            for (int k = lane; k < n; k += 64) acc += col[k] * np[k];
+                            acc = wave_sum(acc);
+                            if (lane == 0) d[j] = acc;
+                        }
                     }
                     __syncthreads();
+                    DSTAMP(3);
                     // z = J2 d2 : one thread per row
                     for (int row = tid; row < n; row += T) {
                         double acc = 0.0;
-                        for (int j = iq; j < n; j++) acc += J[(size_t)j * n + row] * d[j];
+#pragma unroll 8
+                        for (int j = iq; j < n; j++) acc += J[(size_t)j * ldj + row] * d[j];
                         z[row] = acc;
                     }
+                    DSTAMP(4);
                     // r = R^-1 d1 (back substitution, column oriented)
-                    for (int i = tid; i < iq; i += T) r[i] = d[i];
-                    __syncthreads();
-                    for (int k = iq - 1; k >= 0; k--) {
-                        if (tid == 0) r[k] = r[k] / R[(size_t)k * n + k];
+                    if constexpr (LDSJ) {
+                        // n <= 128: wave 0 holds r in two registers per lane and broadcasts
+                        // r_k by readlane -- no barrier inside the chain; the column of R and
+                        // the reciprocal pivot do not depend on the chain and are read ahead
+                        if (wave == 0) {
+                            double r0 = lane < iq ? d[lane] : 0.0, r1 = lane + 64 < iq ? d[lane + 64] : 0.0;
+                            // reciprocal pivots: two per lane, computed side by side ahead of the chain
+                            const double iv0 = lane < iq ? 1.0 / R[ridx(lane, lane)] : 0.0;
+                            const double iv1 = lane + 64 < iq ? 1.0 / R[ridx(lane + 64, lane + 64)] : 0.0;
+                            // eight columns of R per group: their loads are issued together, the
+                            // chain then runs from registers
+                            for (int k0 = iq - 1; k0 >= 0; k0 -= 8) {
+                                double c0v[8], c1v[8];
+#pragma unroll
+                                for (int q8 = 0; q8 < 8; q8++) {
+                                    const int k = k0 - q8;
+                                    c0v[q8] = (k >= 0 && lane < k) ? R[ridx(lane, k)] : 0.0;
+                                    c1v[q8] = (k >= 0 && lane + 64 < k) ? R[ridx(lane + 64, k)] : 0.0;
+                                }
+#pragma unroll
+                                for (int q8 = 0; q8 < 8; q8++) {
+                                    const int k = k0 - q8;
+                                    if (k >= 0) {
+                                        const double ivsel = k >= 64 ? iv1 : iv0;
+                                        const double inv = __hiloint2double(
+                                            __builtin_amdgcn_readlane(__double2hiint(ivsel), k & 63),
+                                            __builtin_amdgcn_readlane(__double2loint(ivsel), k & 63));
+                                        const double rsel = k >= 64 ? r1 : r0;
+                                        const int lo32 = __builtin_amdgcn_readlane(__double2loint(rsel), k & 63);
+                                        const int hi32 = __builtin_amdgcn_readlane(__double2hiint(rsel), k & 63);
+                                        const double rk = __hiloint2double(hi32, lo32) * inv;
+                                        r0 -= c0v[q8] * rk;
+                                        r1 -= c1v[q8] * rk;
+                                        if (lane == (k & 63)) {
+                                            if (k >= 64) r1 = rk;
+                                            else r0 = rk;
+                                        }
+                                    }
+                                }
+                            }
+                            if (lane < iq) r[lane] = r0;
+                            if (lane + 64 < iq) r[lane + 64] = r1;
+                        }
                         __syncthreads();
-                        const double rk = r[k];
-                        for (int i = tid; i < k; i += T) r[i] -= R[(size_t)k * n + i] * rk;
+                    } else {
+                        for (int i = tid; i < iq; i += T) r[i] = d[i];
                         __syncthreads();
+                        for (int k = iq - 1; k >= 0; k--) {
+                            if (tid == 0) r[k] = r[k] / R[ridx(k, k)];
+                            __syncthreads();
+                            const double rk = r[k];
+                            for (int i = tid; i < k; i += T) r[i] -= R[ridx(i, k)] * rk;
+                            __syncthreads();
+                        }
                     }
+                    DSTAMP(5);
                     // step lengths
                     double t1 = DINF;
                     int kmin = 0x7fffffff;
@@ -403,6 +575,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     }
                     const double zz = block_sum(pz, red, tid);
                     const double zn = block_sum(pn, red, tid);
+                    DSTAMP(6);
                     const double t2 = fabs(zz) > EPS ? -s[ip] / zn : DINF;
                     const double t = fmin(t1, t2);
                     if (t >= DINF) {
@@ -431,13 +604,13 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     if (t == t2) {
                         // add_constraint (eiquadprog.hpp:450-513)
                         falg += 6.0 * nn * (nn - iq - 1);
+                        DSTAMP(10);
                         // suffix norms nu_j = ||d[j..n-1]||
-                        if (tid == 0) {
+                        for (int j = iq + tid; j < n; j += T) {
                             double acc = 0.0;
-                            for (int j = n - 1; j >= iq; j--) {
-                                acc += d[j] * d[j];
-                                suf[j] = sqrt(acc);
-                            }
+#pragma unroll 8
+                            for (int i = n - 1; i >= j; i--) acc += d[i] * d[i];
+                            suf[j] = sqrt(acc);
                         }
                         __syncthreads();
                         for (int j = iq + 1 + tid; j < n; j += T) {
@@ -460,21 +633,39 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                             }
                         }
                         __syncthreads();
+                        DSTAMP(11);
                         for (int row = tid; row < n; row += T) {
                             if (n - 1 >= iq + 1) {
-                                double t2c = J[(size_t)(n - 1) * n + row];
-                                for (int j = n - 1; j >= iq + 1; j--) {
-                                    const double t1c = J[(size_t)(j - 1) * n + row];
-                                    if (rx[j] == DINF) {
-                                        J[(size_t)j * n + row] = t2c;
-                                        t2c = t1c;
-                                    } else {
-                                        const double nv = t1c * rc[j] + t2c * rs[j];
-                                        J[(size_t)j * n + row] = rx[j] * (t1c + nv) - t2c;
-                                        t2c = nv;
+                                double t2c = J[(size_t)(n - 1) * ldj + row];
+                                for (int j0 = n - 1; j0 >= iq + 1; j0 -= 8) {
+                                    double t1v[8], outv[8], cv[8], sv[8], xv[8];
+#pragma unroll
+                                    for (int q8 = 0; q8 < 8; q8++) {
+                                        const bool in = j0 - q8 >= iq + 1;
+                                        t1v[q8] = in ? J[(size_t)(j0 - q8 - 1) * ldj + row] : 0.0;
+                                        cv[q8] = in ? rc[j0 - q8] : 1.0;
+                                        sv[q8] = in ? rs[j0 - q8] : 0.0;
+                                        xv[q8] = in ? rx[j0 - q8] : DINF;
                                     }
+#pragma unroll
+                                    for (int q8 = 0; q8 < 8; q8++) {
+                                        const int j = j0 - q8;
+                                        if (j >= iq + 1) {
+                                            if (xv[q8] == DINF) {
+                                                outv[q8] = t2c;
+                                                t2c = t1v[q8];
+                                            } else {
+                                                const double nv = t1v[q8] * cv[q8] + t2c * sv[q8];
+                                                outv[q8] = xv[q8] * (t1v[q8] + nv) - t2c;
+                                                t2c = nv;
+                                            }
+                                        }
+                                    }
+#pragma unroll
+                                    for (int q8 = 0; q8 < 8; q8++)
+                                        if (j0 - q8 >= iq + 1) J[(size_t)(j0 - q8) * ldj + row] = outv[q8];
                                 }
-                                J[(size_t)iq * n + row] = t2c;
+                                J[(size_t)iq * ldj + row] = t2c;
                             }
                         }
                         __syncthreads();
@@ -483,7 +674,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                         }
                         __syncthreads();
                         for (int j = iq + 1 + tid; j < n; j += T) d[j] = 0.0;
-                        for (int i = tid; i <= iq; i += T) R[(size_t)iq * n + i] = d[i];
+                        for (int i = tid; i <= iq; i += T) R[ridx(i, iq)] = d[i];
                         iq++;
                         __syncthreads();
                         const double dq = d[iq - 1];
@@ -503,6 +694,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                             restart = true;
                             break;
                         }
+                        DSTAMP(7);
                         R_norm = fmax(R_norm, fabs(dq));
                         if (tid == 0) iai[ip] = -1;
                         break; // goto l1
@@ -510,13 +702,21 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     // partial step (:434-446)
                     if (tid == 0) iai[l] = l;
                     __syncthreads();
+                    DSTAMP(6);
                     delete_constraint(l);
+                    DSTAMP(8);
                     eval_s(ip);
+                    DSTAMP(1);
                 }
             } while (restart);
         }
         __syncthreads();
 
+        DSTAMP(9);
+#ifdef MPCB_STAMPS
+        if (tid == 0 && sd.dbg)
+            for (int i = 0; i < 12; i++) sd.dbg[(size_t)inst * 12 + i] = stamp_acc[i];
+#endif
         // ---- outputs ---------------------------------------------------------
         const bool solved = status == MPCB_OK || status == MPCB_ITER_CAP;
         if (tid == 0) {
@@ -589,11 +789,13 @@ __global__ void list_all_kernel(int *list, int *count, int B) {
     if (i == 0) *count = B;
 }
 
-size_t dense_lds_bytes(const DevSetup &sd) {
+size_t dense_lds_bytes(const DevSetup &sd, bool ldsj) {
     const size_t N = sd.N, n = sd.axes * N, m = sd.m;
-    size_t doubles = 5 * n + 3 * (n + 1) + 3 * n + (n + 1) + m + 4 * N + (size_t)sd.nphase * 14 + 4;
+    size_t doubles = 5 * n + 3 * (n + 1) + 3 * n + (n + 1) + m + 5 * N + (size_t)sd.nphase * 14 + 4;
     size_t ints = 4 + 2 * (n + 1) + 2 * m;
-    return doubles * 8 + ints * 4 + 64;
+    size_t bytes = doubles * 8 + ints * 4 + 64;
+    if (ldsj) bytes += (n * (n | 1) + n * (n + 3) / 2 + 2) * 8;
+    return bytes;
 }
 
 } // namespace
@@ -606,17 +808,21 @@ hipError_t launch_list_all(const DenseWs &ws, int B, hipStream_t stream) {
 hipError_t launch_dense(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, const DenseWs &ws,
                         int blocks, hipStream_t stream) {
     if (blocks <= 0) return hipSuccess;
-    const size_t shmem = dense_lds_bytes(sd);
     const bool poly = sd.form != MPCB_BOX_1D;
-    const void *fn = poly ? reinterpret_cast<const void *>(dense_kernel<true>)
-                          : reinterpret_cast<const void *>(dense_kernel<false>);
+    // 160 KB of LDS per workgroup at most; keep a margin for the static part
+    const bool ldsj = dense_lds_bytes(sd, true) <= 160 * 1024 - 256;
+    const size_t shmem = dense_lds_bytes(sd, ldsj);
+    const void *fn;
+    if (poly) fn = ldsj ? reinterpret_cast<const void *>(dense_kernel<true, true>)
+                        : reinterpret_cast<const void *>(dense_kernel<true, false>);
+    else fn = ldsj ? reinterpret_cast<const void *>(dense_kernel<false, true>)
+                   : reinterpret_cast<const void *>(dense_kernel<false, false>);
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    if (poly) hipLaunchKernelGGL(dense_kernel<true>, dim3(blocks), dim3(T), shmem, stream, sd, in, out, ws);
-    else hipLaunchKernelGGL(dense_kernel<false>, dim3(blocks), dim3(T), shmem, stream, sd, in, out, ws);
-    return hipGetLastError();
+    void *args[] = {(void *)&sd, (void *)&in, (void *)&out, (void *)&ws};
+    return hipLaunchKernel(fn, dim3(blocks), dim3(T), args, shmem, stream);
 }
 
 } // namespace mpcb
