@@ -140,44 +140,38 @@ __device__ inline void polygon_phase(const DevSetup &sd, const DevIn &in, int in
         corrx[l] = ((c0x + sd.hip[2 * l]) + spx) - fx[l]; // :1234-1237
         corry[l] = ((c0y + sd.hip[2 * l + 1]) + spy) - fy[l];
     }
+    // Feet during phase myph: the first (myph + 1) / 2 steps of the schedule have been taken
+    // (phase 2i = four feet down before step i, phase 2i + 1 = step i under way, its foot
+    // already displaced but excluded from the polygon).  Leg l, at schedule position pos_l,
+    // has swung once for every j < taken with (cur + j) % 4 == pos_l; its displacements are
+    // added one by one in the order the reference adds them, so the sums round identically.
+    const int taken = myph >= 2 * sd.steps ? sd.steps : (myph + 1) >> 1;
     int excl = -1;
-    for (int i = 0; i < sd.steps; i++) {
-        if (myph == 2 * i) {
-#pragma unroll
-            for (int l = 0; l < 4; l++) {
-                sx[l] = fx[l];
-                sy[l] = fy[l];
-            }
-            excl = -1;
-        }
-        const int sw = (cur == 0) ? 0 : (cur == 1) ? 3 : (cur == 2) ? 1 : 2;
-#pragma unroll
-        for (int l = 0; l < 4; l++) {
-            if (l == sw) {
-                const double dx = flag[l] ? corrx[l] : spx; // :1266-1280
-                const double dy = flag[l] ? corry[l] : spy;
-                flag[l] = false;
-                fx[l] += dx;
-                fy[l] += dy;
-            }
-        }
-        if (myph == 2 * i + 1) {
-#pragma unroll
-            for (int l = 0; l < 4; l++) {
-                sx[l] = fx[l];
-                sy[l] = fy[l];
-            }
-            excl = sw;
-        }
-        cur = (cur + 1) & 3;
+    if ((myph & 1) && myph < 2 * sd.steps) {
+        const int c = (cur + (myph >> 1)) & 3;
+        excl = (c == 0) ? 0 : (c == 1) ? 3 : (c == 2) ? 1 : 2;
     }
-    if (myph == 2 * sd.steps) {
+    int nsw[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        const int pos = (l == 0) ? 0 : (l == 3) ? 1 : (l == 1) ? 2 : 3; // LF, RH, RF, LH
+        const int first = (pos - cur) & 3;                              // index of the leg's first swing
+        nsw[l] = taken > first ? (taken - first + 3) >> 2 : 0;
+    }
+    for (int j = 0; j < (sd.steps + 3) >> 2; j++) {
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-            sx[l] = fx[l];
-            sy[l] = fy[l];
+            if (j < nsw[l]) {
+                const bool fl = flag[l] && j == 0; // :1266-1280
+                fx[l] += fl ? corrx[l] : spx;
+                fy[l] += fl ? corry[l] : spy;
+            }
         }
-        excl = -1;
+    }
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        sx[l] = fx[l];
+        sy[l] = fy[l];
     }
     if (myph >= sd.nphase) return;
     const int E = excl < 0 ? 4 : 3;

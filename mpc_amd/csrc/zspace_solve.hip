@@ -20,6 +20,8 @@
 // them, in registers.  Cross-lane data goes through the wave's private LDS slice
 // or through wave shuffles.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <type_traits>
 
 #include "device_common.h"
 #include "kernels.h"
@@ -41,9 +43,16 @@ struct WaveState {
     int oldRow[QL + 1], oldKS[QL + 1];
     int pad[3];
 };
+static_assert(QL <= 64, "one lane per working-set position");
 static_assert(sizeof(WaveState) % 8 == 0, "tab must stay 8-byte aligned");
 
 __device__ __forceinline__ int tri(int col) { return col * (col + 1) / 2; }
+
+// value of v on lane `src` (wave-uniform), without going through LDS
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                            __builtin_amdgcn_readlane(__double2loint(v), src));
+}
 
 // Remove working-set position qq (delete_constraint, eiquadprog.hpp:516-592).
 // R loses column qq and is re-triangularised by Givens rotations of rows (j, j+1);
@@ -90,7 +99,7 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
             const bool act = rk && lane >= j;
             const double bot = act ? W.R[offo + j + 1] : 0.0;
             const double t2 = (ri && lane <= j + 1) ? W.Rinv[tri(j + 1) + lane] : 0.0;
-            const double tj = __shfl(top, j, 64), bj = __shfl(bot, j, 64);
+            const double tj = lane_bcast(top, j), bj = lane_bcast(bot, j);
             const double h = distance(tj, bj);
             wsync();
             if (h == 0.0) {
@@ -142,7 +151,7 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
 // ROWS: polygon rows come from the caller (in.rows_pqr, the (p, q, r) of every row of the
 // A, b that computeSteps returned, possibly edited) instead of being built from the feet.
 template <int NPL, bool POLY, bool ROWS>
-__global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
+__global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
                                                       int *unresolved_list, int *unresolved_count) {
     constexpr int ES = POLY ? 4 : 2;
     extern __shared__ double smem[];
@@ -227,30 +236,37 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
     if (lane < QL + 4) W.wsKS[lane] = 0; // padding entries must name a valid knot
     wsync();
 
-    // v += sum_a coef_a * M[knot_a, :] over the first n working-set rows, four rows'
-    // loads in flight at a time (cx/cy are zero beyond n, so the padding rows add 0)
-    auto accum_rows = [&](const double *M, int n, double *vx, double *vy) {
-        for (int a0 = 0; a0 < n; a0 += 4) {
-            const double *row[4];
-            double ca[4], cb[4], sv[4][NPL];
+    // v += sum_a coef_a * M[knot_a, :] over the first n working-set rows.  The loads of a
+    // whole group of rows (eight while more than four remain, else four) are in flight
+    // together; cx/cy are zero beyond n, so the padding rows add 0.
+    auto accum_group = [&](const double *M, int a0, double *vx, double *vy, auto gtag) {
+        constexpr int G = decltype(gtag)::value;
+        const double *row[G];
+        double ca[G], cb[G], sv[G][NPL];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                row[j] = M + (size_t)(ufirst(W.wsKS[a0 + j]) >> 2) * N;
-                ca[j] = W.cx[a0 + j];
-                cb[j] = W.cy[a0 + j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int c = 0; c < NPL; c++) sv[j][c] = row[j][kc[c]];
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int c = 0; c < NPL; c++) {
-                    vx[c] += ca[j] * sv[j][c];
-                    if constexpr (POLY) vy[c] += cb[j] * sv[j][c];
-                }
+        for (int j = 0; j < G; j++) {
+            row[j] = M + (size_t)(ufirst(W.wsKS[a0 + j]) >> 2) * N;
+            ca[j] = W.cx[a0 + j];
+            cb[j] = W.cy[a0 + j];
         }
+#pragma unroll
+        for (int j = 0; j < G; j++)
+#pragma unroll
+            for (int c = 0; c < NPL; c++) sv[j][c] = row[j][kc[c]];
+#pragma unroll
+        for (int j = 0; j < G; j++)
+#pragma unroll
+            for (int c = 0; c < NPL; c++) {
+                vx[c] += ca[j] * sv[j][c];
+                if constexpr (POLY) vy[c] += cb[j] * sv[j][c];
+            }
+    };
+    auto accum_rows = [&](const double *M, int n, double *vx, double *vy) {
+        int a0 = 0;
+        if constexpr (NPL <= 4) {
+            for (; n - a0 > 4; a0 += 8) accum_group(M, a0, vx, vy, std::integral_constant<int, 8>{});
+        }
+        for (; a0 < n; a0 += 4) accum_group(M, a0, vx, vy, std::integral_constant<int, 4>{});
     };
     // coefficients of the working-set rows: coef * (p, q), zero-padded
     auto set_coefs = [&](double coef, int n) {
@@ -283,10 +299,6 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
         if constexpr (ROWS) return rows[rowIdx(c, e) * 3 + 2];
         else if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3 + 2];
         else return e == 0 ? -lo[c] : hi[c];
-    };
-    auto slotRow = [&](int c, int e) -> int {
-        if constexpr (POLY) return row0[c] + e;
-        else return kn[c] + e * N;
     };
 
     // ---- unconstrained solution (x = -G^-1 g0, eiquadprog.hpp:188-191) ----
@@ -321,8 +333,8 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
     // ---- dual active-set loop ----------------------------------------------
     int iq = 0, iters = 0, passes = 0, status = MPCB_OK;
     // operation count of the dense method along this pivot sequence (diagnostic)
-    const double nn = (double)(N * (POLY ? 2 : 1)), mm = (double)sd.m;
-    double falg = 2.0 * nn * nn;
+    const long long nn = N * (POLY ? 2 : 1), mm = sd.m;
+    long long falg = 2 * nn * nn;
     unsigned actm = 0, exclm = 0;
     double R_norm = 1.0;
     double zx[NPL], zy[NPL];
@@ -351,38 +363,44 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
         // (step 2, :279-287, first pass: ss = 0).  Row values are not kept: the rare
         // restart of step 2 recomputes them from zx, zy.
         double psi = 0.0;
-        double bv0 = DINF;
-        int brow0 = 0x7fffffff, bks0 = 0;
+        double bv0 = 0.0; // only violated rows (v < 0) are candidates
+        int bslot = -1;
         {
-            // every slot's (p, q, r) is loaded first and unconditionally (slots that do not
-            // exist read a valid but meaningless table entry and are masked below), so the
-            // LDS reads overlap instead of serialising behind per-slot branches
-            double sp[NPL][ES], sq[NPL][ES], sr[NPL][ES];
+            // one knot's slots at a time; the (p, q, r) of the next knot are loaded (always,
+            // slots that do not exist read a valid but meaningless entry and are masked
+            // below) while this knot's rows are evaluated
+            double sp[2][ES], sq[2][ES], sr[2][ES];
 #pragma unroll
-            for (int c = 0; c < NPL; c++)
+            for (int e = 0; e < ES; e++) {
+                sp[0][e] = slotP(0, e);
+                sq[0][e] = slotQ(0, e);
+                sr[0][e] = slotR(0, e);
+            }
 #pragma unroll
-                for (int e = 0; e < ES; e++) {
-                    sp[c][e] = slotP(c, e);
-                    sq[c][e] = slotQ(c, e);
-                    sr[c][e] = slotR(c, e);
+            for (int c = 0; c < NPL; c++) {
+                if (c + 1 < NPL) {
+#pragma unroll
+                    for (int e = 0; e < ES; e++) {
+                        sp[(c + 1) & 1][e] = slotP(c + 1, e);
+                        sq[(c + 1) & 1][e] = slotQ(c + 1, e);
+                        sr[(c + 1) & 1][e] = slotR(c + 1, e);
+                    }
                 }
-#pragma unroll
-            for (int c = 0; c < NPL; c++)
 #pragma unroll
                 for (int e = 0; e < ES; e++) {
                     const unsigned bit = 1u << (4 * c + e);
                     const bool valid = (validm & bit) != 0;
-                    const double v = valid ? sp[c][e] * zx[c] + sq[c][e] * zy[c] + sr[c][e] : DINF;
+                    const double v = valid ? sp[c & 1][e] * zx[c] + sq[c & 1][e] * zy[c] + sr[c & 1][e] : DINF;
                     psi += fmin(0.0, v);
-                    const int row = slotRow(c, e);
-                    const bool better = !(actm & bit) && v < 0.0 && (v < bv0 || (v == bv0 && row < brow0));
+                    // rows ascend with (c, e) inside a lane, so the first minimum wins with <
+                    const bool better = !(actm & bit) && v < bv0;
                     bv0 = better ? v : bv0;
-                    brow0 = better ? row : brow0;
-                    bks0 = better ? ((kn[c] << 2) | e) : bks0;
+                    bslot = better ? 4 * c + e : bslot;
                 }
+            }
         }
         psi = wave_sum(psi);
-        falg += 2.0 * mm * nn;
+        falg += 2 * mm * nn;
         exclm = 0xffffffffu; // iaexcl[i] = true (:257)
         if (fabs(psi) <= sd.psi_thr) { // :267-272
             zmp_current = true;
@@ -400,8 +418,15 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
         bool done = false, restart, restart_seen = false;
         do { // step 2 (l2), :279-299
             restart = false;
-            double bv = bv0;
-            int brow = brow0, bks = bks0;
+            double bv = bslot >= 0 ? bv0 : DINF;
+            // ties between lanes go to the lower row: rows ascend with (knot, edge) for the
+            // polygon rows and with (side, knot) for the box rows
+            int brow = 0x7fffffff, bks = 0;
+            if (bslot >= 0) {
+                const int cb = bslot >> 2, eb = bslot & 3;
+                bks = ((lane + 64 * cb) << 2) | eb;
+                brow = POLY ? bks : lane + 64 * cb + eb * N;
+            }
             if (restart_seen) {
                 // second pass of step 2 after a degenerate add: rows below the running
                 // minimum ss that are neither active nor excluded
@@ -415,11 +440,12 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                         const unsigned bit = 1u << (4 * c + e);
                         if ((validm & bit) && !(actm & bit) && (exclm & bit)) {
                             const double v = slotP(c, e) * zx[c] + slotQ(c, e) * zy[c] + slotR(c, e);
-                            const int row = slotRow(c, e);
+                            const int ks = (kn[c] << 2) | e;
+                            const int row = POLY ? ks : kn[c] + e * N;
                             if (v < ssv && (v < bv || (v == bv && row < brow))) {
                                 bv = v;
                                 brow = row;
-                                bks = (kn[c] << 2) | e;
+                                bks = ks;
                             }
                         }
                     }
@@ -428,8 +454,8 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
             STAMP(3);
             if (bv < ssv) {
                 ssv = bv;
-                ipRow = brow;
                 ipKS = bks;
+                ipRow = POLY ? ufirst(sd.knot_row0[bks >> 2]) + (bks & 3) : brow;
                 s_ip = bv;
             }
             if (ssv >= 0.0) {
@@ -439,19 +465,19 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
             }
             const int kip = ipKS >> 2, eip = ipKS & 3;
             if constexpr (ROWS) {
-                pip = rows[ipRow * 3];
-                qip = rows[ipRow * 3 + 1];
+                pip = ufirst(rows[ipRow * 3]);
+                qip = ufirst(rows[ipRow * 3 + 1]);
             } else if constexpr (POLY) {
                 const int php = sd.knot_phase[kip];
-                pip = tab[(php * 4 + eip) * 3];
-                qip = tab[(php * 4 + eip) * 3 + 1];
+                pip = ufirst(tab[(php * 4 + eip) * 3]);
+                qip = ufirst(tab[(php * 4 + eip) * 3 + 1]);
             } else {
                 pip = eip == 0 ? 1.0 : -1.0;
                 qip = 0.0;
             }
             ucand = 0.0; // u(iq) = 0 (:297)
             pending = true;
-            const double mii = (pip * pip + qip * qip) * sd.S[(size_t)kip * N + kip];
+            const double mii = ufirst((pip * pip + qip * qip) * sd.S[(size_t)kip * N + kip]);
 
             for (;;) { // step 2a (l2a), :306-446
                 passes++;
@@ -460,7 +486,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                     done = true;
                     break;
                 }
-                falg += 2.0 * nn * nn + 2.0 * nn * (nn - iq) + (double)iq * iq;
+                falg += 2 * nn * nn + 2 * nn * (nn - iq) + (long long)iq * iq;
                 // g = N_A' G^-1 n_ip ; d = R^-T g (= J1' n_ip) ; r = R^-1 d
                 double ga = 0.0, da = 0.0, ra = 0.0, ua = 0.0;
                 if (lane < iq) {
@@ -491,7 +517,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                     }
                 }
                 STAMP(5);
-                const double zn = mii - wave_sum(da * da); // z . n_ip
+                const double zn = ufirst(mii - wave_sum(da * da)); // z . n_ip
                 // step 2b: t1 = min u_k / r_k over r_k > 0, first minimum wins (:322-334)
                 double t1 = (lane < iq && ra > 0.0) ? ua / ra : DINF;
                 int apos = lane, dummy = 0;
@@ -527,7 +553,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                     done = true;
                     break;
                 }
-                const double t2 = znz ? -s_ip / zn : DINF;
+                const double t2 = znz ? ufirst(-s_ip / zn) : DINF;
                 const double t = fmin(t1, t2);
                 if (t >= DINF) { // :350-356
                     status = MPCB_INFEASIBLE;
@@ -537,29 +563,29 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                 }
                 if (t2 >= DINF) { // dual step only, drop (:358-373)
                     if (lane < iq) W.wsU[lane] = ua - t * ra;
-                    ucand += t;
+                    ucand = ufirst(ucand + t);
                     const int ksd = ufirst(W.wsKS[apos]);
                     if (lane == ((ksd >> 2) & 63)) actm &= ~(1u << (4 * ((ksd >> 2) >> 6) + (ksd & 3)));
                     wsync();
                     {
-                        const double cdrop = (double)(iq - 1 - apos);
-                        falg += 6.0 * nn * cdrop + 3.0 * cdrop * (cdrop - 1.0);
+                        const long long cdrop = iq - 1 - apos;
+                        falg += 6 * nn * cdrop + 3 * cdrop * (cdrop - 1);
                     }
                     drop_constraint(W, lane, iq, apos);
                     continue;
                 }
                 // step in primal and dual space (:377-382)
-                f += t * zn * (0.5 * t + ucand);
+                f = ufirst(f + t * zn * (0.5 * t + ucand));
                 if (lane < iq) W.wsU[lane] = ua - t * ra;
-                ucand += t;
+                ucand = ufirst(ucand + t);
                 if (t == t2) { // full step: add the constraint (:392-426, add_constraint :450-513)
                     if (iq >= QL) {
                         status = STATUS_UNRESOLVED;
                         done = true;
                         break;
                     }
-                    falg += 6.0 * nn * (nn - iq - 1);
-                    const double rho = sqrt(fmax(zn, 0.0));
+                    falg += 6 * nn * (nn - iq - 1);
+                    const double rho = ufirst(sqrt(fmax(zn, 0.0)));
                     if (rho <= EPS * R_norm) {
                         // degenerate: exclude ip, restore u, A (and x) of step 1, retry step 2
                         const int bit = 4 * (kip >> 6) + eip;
@@ -604,15 +630,15 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
                     break; // goto l1
                 }
                 // partial step: drop the blocking constraint and try again (:434-446)
-                s_ip += t * zn;
+                s_ip = ufirst(s_ip + t * zn);
                 {
                     const int ksd = ufirst(W.wsKS[apos]);
                     if (lane == ((ksd >> 2) & 63)) actm &= ~(1u << (4 * ((ksd >> 2) >> 6) + (ksd & 3)));
                 }
                 wsync();
                 {
-                    const double cdrop = (double)(iq - 1 - apos);
-                    falg += 6.0 * nn * cdrop + 3.0 * cdrop * (cdrop - 1.0);
+                    const long long cdrop = iq - 1 - apos;
+                    falg += 6 * nn * cdrop + 3 * cdrop * (cdrop - 1);
                 }
                 drop_constraint(W, lane, iq, apos);
             }
@@ -631,7 +657,7 @@ __global__ __launch_bounds__(256) void zspace_kernel(DevSetup sd, DevIn in, mpcb
         if (out.status) out.status[inst] = status;
         if (out.iters) out.iters[inst] = iters;
         if (out.n_active) out.n_active[inst] = iq;
-        if (out.alg_flops) out.alg_flops[inst] = falg + (POLY ? 2.0 * mm * nn : 0.0);
+        if (out.alg_flops) out.alg_flops[inst] = (double)(falg + (POLY ? 2 * mm * nn : 0));
     }
     if (out.active_idx || out.multipliers) {
         for (int a = lane; a < out.active_stride; a += 64) {
@@ -722,7 +748,8 @@ template <int NPL, bool POLY, bool ROWS>
 hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
                       const DenseWs &ws, hipStream_t stream) {
     const size_t per_wave = sizeof(WaveState) + (POLY ? (size_t)sd.nphase * 14 * 8 : 0);
-    const size_t shmem = 4 * per_wave;
+    size_t shmem = 4 * per_wave;
+    if (const char *pad = getenv("MPCB_EXPERIMENT_LDS_PAD")) shmem += (size_t)atoi(pad);
     auto kfn = zspace_kernel<NPL, POLY, ROWS>;
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
