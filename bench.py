@@ -42,6 +42,25 @@ FP64_FLOP_PER_CLK_PER_CU = 128
 HBM_PEAK_GBS = 8000.0
 
 
+def measured_profile(workload):
+    """Counter-derived figures of an earlier rocprofv3 run of this same command, condensed by
+    scripts/summarize_profile.py into profiles/<round>/<workload>_summary.json (the newest
+    round that has one wins).  Returns (summary of the dominant kernel, file) or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", workload + "_summary.json")))
+    if not files:
+        return None, None
+    try:
+        data = json.load(open(files[-1]))
+        kernels = data.get("kernels", {})
+        name = max(kernels, key=lambda k: kernels[k].get("avg_us", 0.0) * kernels[k].get("calls", 0))
+        k = dict(kernels[name])
+        k["kernel"] = name
+        return k, os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def fp64_vector_peak_tflops(dev):
     props = torch.cuda.get_device_properties(dev)
     cus = props.multi_processor_count
@@ -96,6 +115,18 @@ class CoupledWorkload:
                               i["swing0"][:sample], nthreads=threads)
         dt = time.perf_counter() - t
         return sample / dt, ref
+
+    def cpu_structured(self, threads, sample):
+        from oracle import oracle as O
+        p = O.params(self.N, R=0.01, Q=1.0, Qs=100.0, height=0.5, dense=0, iter_cap=0)
+        oform = {P.COUPLED_VEL: O.COUPLED_VEL, P.COUPLED_JERK: O.COUPLED_JERK,
+                 P.COUPLED_REF: O.COUPLED_REF}[self.form]
+        i = self.inputs
+        t = time.perf_counter()
+        O.coupled_batch(p, oform, self.steps_per_plan, 1000, i["x0"][:sample], i["y0"][:sample],
+                        i["speed"][:sample], i["feet_x"][:sample], i["feet_y"][:sample],
+                        i["swing0"][:sample], nthreads=threads)
+        return sample / (time.perf_counter() - t)
 
 
 class ReplanningWorkload:
@@ -202,6 +233,9 @@ def main():
     ap.add_argument("--workload", default="coupled_vel",
                     choices=("coupled_vel", "coupled_jerk", "coupled_ref", "decoupled", "replanning"))
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (0 = workload default)")
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="nccl (= RCCL) for one rank per GPU; gloo lets several ranks share a GPU "
+                         "for rehearsals")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="instances timed on the host cores (0 disables, -1 = default)")
     args = ap.parse_args()
@@ -213,8 +247,12 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     dev = local if distributed else 0
     torch.cuda.set_device(dev)
 
@@ -252,7 +290,8 @@ def main():
     elapsed = t1 - t0
     dev_ms = ev0.elapsed_time(ev1)  # device time of the K steps on the launch stream
     if distributed:
-        tt = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed, dev_ms], dtype=torch.float64,
+                          device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = tt[0].item(), tt[1].item()
 
@@ -300,11 +339,22 @@ def main():
             },
             "solver": {
                 "status_counts": np.bincount(status, minlength=4).tolist(),
+                "working_set_histogram": np.bincount(n_active).tolist(),
                 "working_set_mean": float(n_active.mean()),
                 "working_set_max": int(n_active.max()),
                 "outer_iterations_mean": float(iters.mean()),
             },
         }
+        prof, prof_file = measured_profile(args.workload)
+        if prof is not None:
+            r = line["roofline"]
+            r["traffic"] = prof.get("hbm_traffic_bytes_per_launch")
+            r["traffic_unit"] = "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)"
+            r["algorithmic_bytes_per_launch"] = wl.alg_bytes / wl.launches
+            r["executed_f64_gflop_per_launch"] = (prof.get("executed_f64_flops_per_launch") or 0.0) / 1e9 or None
+            r["profiled_kernel"] = prof.get("kernel")
+            r["profiled_kernel_avg_ms"] = (prof.get("avg_us") or 0.0) / 1e3 or None
+            r["profile_source"] = prof_file
         sample = args.cpu_sample
         if sample < 0:
             sample = 2048 if args.workload == "decoupled" else 192
@@ -319,6 +369,13 @@ def main():
                 "per_core": rate / threads,
             }
             line["speedup_vs_cpu_baseline"] = value / rate
+            if hasattr(wl, "cpu_structured"):
+                srate = wl.cpu_structured(threads, sample)
+                line["cpu_structured"] = {
+                    "value": srate, "unit": wl.unit, "cores": threads,
+                    "note": "same restatement with its zero-skipping matrix products (identical "
+                            "results); shows how much of the ratio is avoided arithmetic",
+                }
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()

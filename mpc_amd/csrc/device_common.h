@@ -28,6 +28,18 @@ __device__ __forceinline__ double ufirst(double v) {
 // Cross-lane reductions on DPP (data-parallel primitives: lane permutes inside the VALU,
 // no LDS crossbar).  All 64 lanes must be active.  Control codes (gfx9): quad_perm 0x00-0xFF,
 // row_half_mirror 0x141, row_mirror 0x140, row_bcast15 0x142, row_bcast31 0x143.
+// Permutes whose source lane always exists (quad_perm, mirrors over all rows): the previous
+// value of the destination is irrelevant, which saves the copy in front of each move.
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm_f64(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_perm_i32(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_f64(double old, double v) {
     const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
@@ -48,10 +60,10 @@ __device__ __forceinline__ double lane63(double v) {
 // Sum over the wave; the result is wave-uniform.  Butterfly inside each row of 16 lanes,
 // then row totals are chained into lane 63.
 __device__ __forceinline__ double wave_sum(double v) {
-    v += dpp_f64<0xB1, 0xF>(v, v);  // quad_perm [1,0,3,2]
-    v += dpp_f64<0x4E, 0xF>(v, v);  // quad_perm [2,3,0,1]
-    v += dpp_f64<0x141, 0xF>(v, v); // row_half_mirror
-    v += dpp_f64<0x140, 0xF>(v, v); // row_mirror
+    v += dpp_perm_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_perm_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_perm_f64<0x141>(v); // row_half_mirror
+    v += dpp_perm_f64<0x140>(v); // row_mirror
     v += dpp_f64<0x142, 0xA>(0.0, v); // row_bcast15 -> rows 1, 3
     v += dpp_f64<0x143, 0xC>(0.0, v); // row_bcast31 -> rows 2, 3
     return lane63(v);
@@ -59,20 +71,20 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // NaN-ignoring minimum (fmin), like the reference's `<` comparisons that never pick a NaN.
 __device__ __forceinline__ double wave_min(double v) {
-    v = fmin(v, dpp_f64<0xB1, 0xF>(v, v));
-    v = fmin(v, dpp_f64<0x4E, 0xF>(v, v));
-    v = fmin(v, dpp_f64<0x141, 0xF>(v, v));
-    v = fmin(v, dpp_f64<0x140, 0xF>(v, v));
+    v = fmin(v, dpp_perm_f64<0xB1>(v));
+    v = fmin(v, dpp_perm_f64<0x4E>(v));
+    v = fmin(v, dpp_perm_f64<0x141>(v));
+    v = fmin(v, dpp_perm_f64<0x140>(v));
     v = fmin(v, dpp_f64<0x142, 0xA>(DINF, v));
     v = fmin(v, dpp_f64<0x143, 0xC>(DINF, v));
     return lane63(v);
 }
 
 __device__ __forceinline__ int wave_min(int v) {
-    v = min(v, dpp_i32<0xB1, 0xF>(v, v));
-    v = min(v, dpp_i32<0x4E, 0xF>(v, v));
-    v = min(v, dpp_i32<0x141, 0xF>(v, v));
-    v = min(v, dpp_i32<0x140, 0xF>(v, v));
+    v = min(v, dpp_perm_i32<0xB1>(v));
+    v = min(v, dpp_perm_i32<0x4E>(v));
+    v = min(v, dpp_perm_i32<0x141>(v));
+    v = min(v, dpp_perm_i32<0x140>(v));
     v = min(v, dpp_i32<0x142, 0xA>(0x7fffffff, v));
     v = min(v, dpp_i32<0x143, 0xC>(0x7fffffff, v));
     return __builtin_amdgcn_readlane(v, 63);

@@ -164,11 +164,11 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
     long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
-    const int tab_doubles = POLY ? sd.nphase * 14 : 0;
+    const int tab_doubles = POLY ? sd.nphase * 14 + 12 : 0; // one padding phase after the last
     const int per_wave = (int)(sizeof(WaveState) / 8) + tab_doubles;
     WaveState &W = *reinterpret_cast<WaveState *>(smem + (size_t)wv * per_wave);
     double *tab = smem + (size_t)wv * per_wave + sizeof(WaveState) / 8; // [phase][edge][p,q,r]
-    double *cref = tab + (POLY ? sd.nphase * 12 : 0);                    // [phase][x,y] ZMP reference
+    double *cref = tab + (POLY ? (sd.nphase + 1) * 12 : 0);              // [phase][x,y] ZMP reference
 
     // ---- owned knots ------------------------------------------------------
     int kn[NPL], kc[NPL];
@@ -214,6 +214,19 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                 polygon_phase(sd, in, inst, wx[3], wy[3], pbase + lane, tab, cref);
         if (in.zref_phase)
             for (int i = lane; i < 2 * sd.nphase; i += 64) cref[i] = in.zref_phase[(size_t)inst * 2 * sd.nphase + i];
+        if constexpr (!ROWS) {
+            // Rows that do not exist evaluate to +inf without a test: the fourth edge of a
+            // three-foot phase, and every edge of the padding phase that the lanes past
+            // the horizon point at, read (p, q, r) = (0, 0, +inf).
+            for (int pb = lane; pb <= sd.nphase; pb += 64) {
+                const bool three = (pb & 1) && pb < 2 * sd.steps;
+                for (int e = (pb == sd.nphase ? 0 : three ? 3 : 4); e < 4; e++) {
+                    tab[(pb * 4 + e) * 3] = 0.0;
+                    tab[(pb * 4 + e) * 3 + 1] = 0.0;
+                    tab[(pb * 4 + e) * 3 + 2] = DINF;
+                }
+            }
+        }
 #pragma unroll
         for (int c = 0; c < NPL; c++) {
             ph[c] = sd.knot_phase[kc[c]];
@@ -221,6 +234,8 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
             if (kn[c] < N) {
                 const int E = ((ph[c] & 1) && ph[c] < 2 * sd.steps) ? 3 : 4;
                 validm |= ((1u << E) - 1u) << (4 * c);
+            } else if (!ROWS) {
+                ph[c] = sd.nphase;
             }
         }
     } else {
@@ -230,6 +245,9 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                 lo[c] = in.zmin[(size_t)inst * N + kn[c]];
                 hi[c] = in.zmax[(size_t)inst * N + kn[c]];
                 validm |= 3u << (4 * c);
+            } else { // rows past the horizon evaluate to +inf
+                lo[c] = -DINF;
+                hi[c] = DINF;
             }
         }
     }
@@ -362,13 +380,12 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
         // s(x) for every row (:255-261), fused with the search for the most violated row
         // (step 2, :279-287, first pass: ss = 0).  Row values are not kept: the rare
         // restart of step 2 recomputes them from zx, zy.
-        double psi = 0.0;
-        double bv0 = 0.0; // only violated rows (v < 0) are candidates
-        int bslot = -1;
+        double psi = 0.0, mloc = DINF;
+        double sv[NPL][ES];
         {
-            // one knot's slots at a time; the (p, q, r) of the next knot are loaded (always,
-            // slots that do not exist read a valid but meaningless entry and are masked
-            // below) while this knot's rows are evaluated
+            // one knot's slots at a time; the (p, q, r) of the next knot are loaded while this
+            // knot's rows are evaluated.  Slots that do not exist evaluate to +inf (through
+            // their table entries, or masked for caller-built rows).
             double sp[2][ES], sq[2][ES], sr[2][ES];
 #pragma unroll
             for (int e = 0; e < ES; e++) {
@@ -388,14 +405,11 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                 }
 #pragma unroll
                 for (int e = 0; e < ES; e++) {
-                    const unsigned bit = 1u << (4 * c + e);
-                    const bool valid = (validm & bit) != 0;
-                    const double v = valid ? sp[c & 1][e] * zx[c] + sq[c & 1][e] * zy[c] + sr[c & 1][e] : DINF;
+                    double v = fma(sp[c & 1][e], zx[c], fma(sq[c & 1][e], zy[c], sr[c & 1][e]));
+                    if constexpr (ROWS) v = (validm & (1u << (4 * c + e))) ? v : DINF;
+                    sv[c][e] = v;
                     psi += fmin(0.0, v);
-                    // rows ascend with (c, e) inside a lane, so the first minimum wins with <
-                    const bool better = !(actm & bit) && v < bv0;
-                    bv0 = better ? v : bv0;
-                    bslot = better ? 4 * c + e : bslot;
+                    mloc = fmin(mloc, v);
                 }
             }
         }
@@ -418,18 +432,43 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
         bool done = false, restart, restart_seen = false;
         do { // step 2 (l2), :279-299
             restart = false;
-            double bv = bslot >= 0 ? bv0 : DINF;
-            // ties between lanes go to the lower row: rows ascend with (knot, edge) for the
-            // polygon rows and with (side, knot) for the box rows
+            // Most violated row (:279-287).  First pass: the wave minimum of all row values,
+            // then the lowest row attaining it (rows ascend with (knot, edge) for the polygon
+            // rows and with (side, knot) for the box rows).  If that row is in the working set
+            // -- its value is a rounding residue -- the masked search below decides instead.
+            double bv = DINF;
             int brow = 0x7fffffff, bks = 0;
-            if (bslot >= 0) {
-                const int cb = bslot >> 2, eb = bslot & 3;
-                bks = ((lane + 64 * cb) << 2) | eb;
-                brow = POLY ? bks : lane + 64 * cb + eb * N;
+            bool masked = restart_seen;
+            if (!masked) {
+                const double mw = wave_min(mloc);
+                if (mw < 0.0) {
+                    int slot = -1;
+                    if constexpr (POLY) {
+#pragma unroll
+                        for (int c = NPL - 1; c >= 0; c--)
+#pragma unroll
+                            for (int e = ES - 1; e >= 0; e--) slot = sv[c][e] == mw ? 4 * c + e : slot;
+                    } else {
+#pragma unroll
+                        for (int e = ES - 1; e >= 0; e--)
+#pragma unroll
+                            for (int c = NPL - 1; c >= 0; c--) slot = sv[c][e] == mw ? 4 * c + e : slot;
+                    }
+                    const int ks = ((lane + 64 * (slot >> 2)) << 2) | (slot & 3);
+                    const int key = slot < 0 ? 0x7fffffff : POLY ? ks : lane + 64 * (slot >> 2) + (slot & 3) * N;
+                    const int kmin = wave_min(key);
+                    const unsigned long long win = __ballot(key == kmin);
+                    const int src = __ffsll((long long)win) - 1;
+                    const int act = __builtin_amdgcn_readlane((int)((actm >> (slot & 31)) & 1u), src);
+                    bks = __builtin_amdgcn_readlane(ks, src);
+                    brow = kmin;
+                    bv = mw;
+                    masked = act != 0;
+                }
             }
-            if (restart_seen) {
-                // second pass of step 2 after a degenerate add: rows below the running
-                // minimum ss that are neither active nor excluded
+            if (masked) {
+                // rows below the running minimum ss that are neither active nor excluded (the
+                // second pass of step 2 after a degenerate add ends up here as well)
                 bv = DINF;
                 brow = 0x7fffffff;
                 bks = 0;
@@ -439,7 +478,7 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                     for (int e = 0; e < ES; e++) {
                         const unsigned bit = 1u << (4 * c + e);
                         if ((validm & bit) && !(actm & bit) && (exclm & bit)) {
-                            const double v = slotP(c, e) * zx[c] + slotQ(c, e) * zy[c] + slotR(c, e);
+                            const double v = fma(slotP(c, e), zx[c], fma(slotQ(c, e), zy[c], slotR(c, e)));
                             const int ks = (kn[c] << 2) | e;
                             const int row = POLY ? ks : kn[c] + e * N;
                             if (v < ssv && (v < bv || (v == bv && row < brow))) {
@@ -449,8 +488,8 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                             }
                         }
                     }
+                wave_argmin(bv, brow, bks);
             }
-            wave_argmin(bv, brow, bks);
             STAMP(3);
             if (bv < ssv) {
                 ssv = bv;
@@ -747,7 +786,7 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
 template <int NPL, bool POLY, bool ROWS>
 hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
                       const DenseWs &ws, hipStream_t stream) {
-    const size_t per_wave = sizeof(WaveState) + (POLY ? (size_t)sd.nphase * 14 * 8 : 0);
+    const size_t per_wave = sizeof(WaveState) + (POLY ? ((size_t)sd.nphase * 14 + 12) * 8 : 0);
     size_t shmem = 4 * per_wave;
     if (const char *pad = getenv("MPCB_EXPERIMENT_LDS_PAD")) shmem += (size_t)atoi(pad);
     auto kfn = zspace_kernel<NPL, POLY, ROWS>;
