@@ -31,12 +31,16 @@ namespace {
 
 constexpr int QL = 32;                   // capacity of the LDS-resident factor
 constexpr int TRI = QL * (QL + 1) / 2;   // packed upper triangle, column-major
+constexpr int LDI = QL + 1;
 
 struct WaveState {
     double R[TRI];
-    double Rinv[TRI];
+    // R^-1 as a full square with leading dimension LDI (odd: a column read by rows is
+    // conflict-free).  Everything outside the leading iq x iq upper triangle is kept zero, so
+    // the products with it need no masks.
+    double Rinv[QL * LDI];
     double wsU[QL + 1], wsP[QL + 1], wsQ[QL + 1];       // working set: multiplier, p, q
-    double oldU[QL + 1], oldP[QL + 1], oldQ[QL + 1];    // copy taken at step 1 (eiquadprog.hpp:275-277)
+    double oldU[QL + 1];                                // copy taken at step 1 (eiquadprog.hpp:275-277)
     double g[QL + 1], d[QL + 1];
     double cx[QL + 4], cy[QL + 4];                      // row coefficients, zero-padded to a multiple of 4
     int wsRow[QL + 1], wsKS[QL + 4];                    // constraint row; (knot << 2) | slot
@@ -79,26 +83,33 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
         W.wsKS[lane - 1] = tks;
     }
     const int last = iq - 2; // new column / rotation index runs qq .. iq-2
+    const bool ri = lane < iq;
     if (qq <= last) {
         // R: lane k builds new column k from old column k+1
         const bool rk = lane >= qq && lane <= last;
-        const int offn = tri(lane), offo = tri(lane + 1);
-        for (int i = 0; i < qq; i++) {
-            double v = 0;
-            if (rk) v = W.R[offo + i];
+        const int lq = lane < QL - 1 ? lane : QL - 2;
+        const int offn = tri(lq), offo = tri(lq + 1);
+        // rows above qq are not touched by the rotations: plain copy, eight rows per group
+        // (all loads of a group are issued before its stores, the wave runs in lockstep)
+        for (int i0 = 0; i0 < qq; i0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int q8 = 0; q8 < 8; q8++) v[q8] = (rk && i0 + q8 < qq) ? W.R[offo + i0 + q8] : 0.0;
             wsync();
-            if (rk) W.R[offn + i] = v;
+#pragma unroll
+            for (int q8 = 0; q8 < 8; q8++)
+                if (rk && i0 + q8 < qq) W.R[offn + i0 + q8] = v[q8];
         }
         double top = rk ? W.R[offo + qq] : 0.0;
-        // R^-1: lane i carries row i
-        const bool ri = lane < iq;
-        double tcur = (ri && lane <= qq) ? W.Rinv[tri(qq) + lane] : 0.0;
+        // R^-1: lane i carries row i; rows below qq move up by one
+        const int li = lane < QL ? lane : QL - 1;
+        double tcur = (ri && lane <= qq) ? W.Rinv[li * LDI + qq] : 0.0;
         const int inew = lane < qq ? lane : lane - 1;
         wsync();
         for (int j = qq; j <= last; j++) {
             const bool act = rk && lane >= j;
             const double bot = act ? W.R[offo + j + 1] : 0.0;
-            const double t2 = (ri && lane <= j + 1) ? W.Rinv[tri(j + 1) + lane] : 0.0;
+            const double t2 = (ri && lane <= j + 1) ? W.Rinv[li * LDI + j + 1] : 0.0;
             const double tj = lane_bcast(top, j), bj = lane_bcast(bot, j);
             const double h = distance(tj, bj);
             wsync();
@@ -107,7 +118,7 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
                     W.R[offn + j] = top;
                     top = bot;
                 }
-                if (ri && lane != qq && inew <= j) W.Rinv[tri(j) + inew] = tcur;
+                if (ri && lane != qq && inew <= j) W.Rinv[inew * LDI + j] = tcur;
                 tcur = t2;
                 continue;
             }
@@ -125,10 +136,12 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
                     top = ss * top - cc * bot;
                 }
             }
-            if (ri && lane != qq && inew <= j) W.Rinv[tri(j) + inew] = cc * tcur + ss * t2;
+            if (ri && lane != qq && inew <= j) W.Rinv[inew * LDI + j] = cc * tcur + ss * t2;
             tcur = ss * tcur - cc * t2;
         }
     }
+    wsync();
+    if (ri) W.Rinv[lane * LDI + iq - 1] = 0.0; // the vacated last column
     iq--;
     wsync();
 }
@@ -252,6 +265,7 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
         }
     }
     if (lane < QL + 4) W.wsKS[lane] = 0; // padding entries must name a valid knot
+    for (int i = lane; i < QL * LDI; i += 64) W.Rinv[i] = 0.0;
     wsync();
 
     // v += sum_a coef_a * M[knot_a, :] over the first n working-set rows.  The loads of a
@@ -380,9 +394,18 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
         // s(x) for every row (:255-261), fused with the search for the most violated row
         // (step 2, :279-287, first pass: ss = 0).  Row values are not kept: the rare
         // restart of step 2 recomputes them from zx, zy.
+        // mloc / mslot: this lane's lowest row value and the first slot (in row order: rows
+        // ascend with (knot, edge) for the polygon rows, with (side, knot) for the box rows)
+        // that attains it
         double psi = 0.0, mloc = DINF;
-        double sv[NPL][ES];
-        {
+        int mslot = -1;
+        auto visit = [&](int c, int e, double v) {
+            psi += fmin(0.0, v);
+            const bool better = v < mloc;
+            mloc = better ? v : mloc;
+            mslot = better ? 4 * c + e : mslot;
+        };
+        if constexpr (POLY) {
             // one knot's slots at a time; the (p, q, r) of the next knot are loaded while this
             // knot's rows are evaluated.  Slots that do not exist evaluate to +inf (through
             // their table entries, or masked for caller-built rows).
@@ -407,11 +430,14 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                 for (int e = 0; e < ES; e++) {
                     double v = fma(sp[c & 1][e], zx[c], fma(sq[c & 1][e], zy[c], sr[c & 1][e]));
                     if constexpr (ROWS) v = (validm & (1u << (4 * c + e))) ? v : DINF;
-                    sv[c][e] = v;
-                    psi += fmin(0.0, v);
-                    mloc = fmin(mloc, v);
+                    visit(c, e, v);
                 }
             }
+        } else {
+#pragma unroll
+            for (int e = 0; e < ES; e++)
+#pragma unroll
+                for (int c = 0; c < NPL; c++) visit(c, e, e == 0 ? zx[c] - lo[c] : hi[c] - zx[c]);
         }
         psi = wave_sum(psi);
         falg += 2 * mm * nn;
@@ -422,8 +448,6 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
         }
         if (lane < iq) { // :275-277
             W.oldU[lane] = W.wsU[lane];
-            W.oldP[lane] = W.wsP[lane];
-            W.oldQ[lane] = W.wsQ[lane];
             W.oldRow[lane] = W.wsRow[lane];
             W.oldKS[lane] = W.wsKS[lane];
         }
@@ -442,18 +466,7 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
             if (!masked) {
                 const double mw = wave_min(mloc);
                 if (mw < 0.0) {
-                    int slot = -1;
-                    if constexpr (POLY) {
-#pragma unroll
-                        for (int c = NPL - 1; c >= 0; c--)
-#pragma unroll
-                            for (int e = ES - 1; e >= 0; e--) slot = sv[c][e] == mw ? 4 * c + e : slot;
-                    } else {
-#pragma unroll
-                        for (int e = ES - 1; e >= 0; e--)
-#pragma unroll
-                            for (int c = NPL - 1; c >= 0; c--) slot = sv[c][e] == mw ? 4 * c + e : slot;
-                    }
+                    const int slot = mloc == mw ? mslot : -1;
                     const int ks = ((lane + 64 * (slot >> 2)) << 2) | (slot & 3);
                     const int key = slot < 0 ? 0x7fffffff : POLY ? ks : lane + 64 * (slot >> 2) + (slot & 3) * N;
                     const int kmin = wave_min(key);
@@ -537,23 +550,18 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                 wsync();
                 STAMP(4);
                 {
-                    // loads are unconditional (clamped addresses) so they can be issued ahead
+                    // d_i = sum_j Rinv[j][i] g_j, r_i = sum_k Rinv[i][k] d_k: plain sums, the
+                    // zeros of Rinv, g and d take care of the triangle and of lanes >= iq
                     const int lq = lane < QL ? lane : QL - 1;
-                    const int off = tri(lq);
+                    const double *col = W.Rinv + lq, *rowp = W.Rinv + lq * LDI;
 #pragma unroll 4
-                    for (int j = 0; j < iq; j++) {
-                        const double gj = W.g[j];
-                        const double rv = W.Rinv[off + (j <= lq ? j : lq)];
-                        da += (lane < iq && j <= lane) ? rv * gj : 0.0;
-                    }
+                    for (int j = 0; j < iq; j++) da = fma(col[j * LDI], W.g[j], da);
+                    da = lane < iq ? da : 0.0;
                     W.d[lane < QL ? lane : QL] = da;
                     wsync();
 #pragma unroll 4
-                    for (int k = 0; k < iq; k++) {
-                        const double dk = W.d[k];
-                        const double rv = W.Rinv[tri(k) + (lq <= k ? lq : k)];
-                        ra += (lane < iq && k >= lane) ? rv * dk : 0.0;
-                    }
+                    for (int k = 0; k < iq; k++) ra = fma(rowp[k], W.d[k], ra);
+                    ra = lane < iq ? ra : 0.0;
                 }
                 STAMP(5);
                 const double zn = ufirst(mii - wave_sum(da * da)); // z . n_ip
@@ -632,8 +640,22 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                         wsync();
                         if (lane < iq) {
                             W.wsU[lane] = W.oldU[lane];
-                            W.wsP[lane] = W.oldP[lane];
-                            W.wsQ[lane] = W.oldQ[lane];
+                            // (p, q) of the restored row, from where they were first taken
+                            const int oks = W.oldKS[lane];
+                            double op, oq;
+                            if constexpr (ROWS) {
+                                op = rows[W.oldRow[lane] * 3];
+                                oq = rows[W.oldRow[lane] * 3 + 1];
+                            } else if constexpr (POLY) {
+                                const int oph = sd.knot_phase[oks >> 2];
+                                op = tab[(oph * 4 + (oks & 3)) * 3];
+                                oq = tab[(oph * 4 + (oks & 3)) * 3 + 1];
+                            } else {
+                                op = (oks & 3) == 0 ? 1.0 : -1.0;
+                                oq = 0.0;
+                            }
+                            W.wsP[lane] = op;
+                            W.wsQ[lane] = oq;
                             W.wsRow[lane] = W.oldRow[lane];
                             W.wsKS[lane] = W.oldKS[lane];
                         }
@@ -650,12 +672,13 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                     }
                     R_norm = fmax(R_norm, rho);
                     const int off = tri(iq);
+                    const double irho = 1.0 / rho;
                     if (lane < iq) {
                         W.R[off + lane] = da;
-                        W.Rinv[off + lane] = -ra / rho;
+                        W.Rinv[lane * LDI + iq] = -ra * irho;
                     } else if (lane == iq) {
                         W.R[off + iq] = rho;
-                        W.Rinv[off + iq] = 1.0 / rho;
+                        W.Rinv[iq * LDI + iq] = irho;
                         W.wsU[iq] = ucand;
                         W.wsP[iq] = pip;
                         W.wsQ[iq] = qip;
