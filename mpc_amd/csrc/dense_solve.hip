@@ -106,7 +106,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
     for (int entry = blockIdx.x; entry < count; entry += gridDim.x) {
         const int inst = ws.list[entry];
 #ifdef MPCB_STAMPS
-        long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        long long stamp_acc[16] = {0};
         long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
         double *J, *R; // J column-major n x ldj; R upper triangular plus one sub-diagonal
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
         DSTAMP(9);
 #ifdef MPCB_STAMPS
         if (tid == 0 && sd.dbg)
-            for (int i = 0; i < 12; i++) sd.dbg[(size_t)inst * 12 + i] = stamp_acc[i];
+            for (int i = 0; i < 16; i++) sd.dbg[(size_t)inst * 16 + i] = stamp_acc[i];
 #endif
         // ---- outputs ---------------------------------------------------------
         const bool solved = status == MPCB_OK || status == MPCB_ITER_CAP;

@@ -103,6 +103,27 @@ __device__ __forceinline__ void wave_argmin(double &val, int &key, int &aux) {
     key = k;
 }
 
+// s = sqrt(x) and is = 1/sqrt(x) for x > 0 from ONE dependent chain (hardware reciprocal
+// square root estimate + two coupled Goldschmidt steps + one residual correction each), accurate
+// to about an ulp.  A correctly rounded sqrt followed by a division costs more than twice as
+// many dependent instructions, and these sit on the critical path of every pass.
+__device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &is) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    const double y2 = h + h;
+    const double e = fma(-g, y2, 1.0);
+    s = g;
+    is = fma(y2, e, y2);
+}
+
 // eiquadprog.hpp:90-108
 __device__ __forceinline__ double distance(double a, double b) {
     const double a1 = fabs(a), b1 = fabs(b);

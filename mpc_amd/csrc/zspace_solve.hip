@@ -111,7 +111,10 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
             const double bot = act ? W.R[offo + j + 1] : 0.0;
             const double t2 = (ri && lane <= j + 1) ? W.Rinv[li * LDI + j + 1] : 0.0;
             const double tj = lane_bcast(top, j), bj = lane_bcast(bot, j);
-            const double h = distance(tj, bj);
+            // h = hypot(tj, bj) (distance(), eiquadprog.hpp:90-108) and 1/h from one chain
+            const double hh = tj * tj + bj * bj;
+            double h = 0.0, ih = 0.0;
+            if (hh > 0.0) sqrt_rsqrt(hh, h, ih);
             wsync();
             if (h == 0.0) {
                 if (act) {
@@ -122,7 +125,7 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
                 tcur = t2;
                 continue;
             }
-            double cc = tj / h, ss = bj / h, hd = h;
+            double cc = tj * ih, ss = bj * ih, hd = h;
             if (cc < 0.0) {
                 cc = -cc;
                 ss = -ss;
@@ -147,7 +150,7 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
 }
 
 // Diagnostic build only (-DMPCB_STAMPS): cycles per section, summed per instance into
-// sd.dbg[inst*10 + section].  No stamp executes in the normal build.
+// sd.dbg[inst*16 + section].  No stamp executes in the normal build.
 #ifdef MPCB_STAMPS
 #define STAMP(i)                                         \
     do {                                                 \
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
     if (inst >= B) return;
     const int N = sd.N;
 #ifdef MPCB_STAMPS
-    long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_acc[16] = {0};
     long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     const int tab_doubles = POLY ? sd.nphase * 14 + 12 : 0; // one padding phase after the last
@@ -565,6 +568,14 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                 }
                 STAMP(5);
                 const double zn = ufirst(mii - wave_sum(da * da)); // z . n_ip
+                // rho = sqrt(zn) is the new diagonal entry of R if the constraint is added; its
+                // reciprocal also gives the full step length t2 = -s_ip / zn without a division
+                double rho = 0.0, irho = 0.0;
+                if (zn > 0.0) {
+                    sqrt_rsqrt(zn, rho, irho);
+                    rho = ufirst(rho);
+                    irho = ufirst(irho);
+                }
                 // step 2b: t1 = min u_k / r_k over r_k > 0, first minimum wins (:322-334)
                 double t1 = (lane < iq && ra > 0.0) ? ua / ra : DINF;
                 int apos = lane, dummy = 0;
@@ -600,8 +611,9 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                     done = true;
                     break;
                 }
-                const double t2 = znz ? ufirst(-s_ip / zn) : DINF;
+                const double t2 = znz ? ufirst(-s_ip * irho * irho) : DINF;
                 const double t = fmin(t1, t2);
+                STAMP(9);
                 if (t >= DINF) { // :350-356
                     status = MPCB_INFEASIBLE;
                     f = DINF;
@@ -632,7 +644,6 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                         break;
                     }
                     falg += 6 * nn * (nn - iq - 1);
-                    const double rho = ufirst(sqrt(fmax(zn, 0.0)));
                     if (rho <= EPS * R_norm) {
                         // degenerate: exclude ip, restore u, A (and x) of step 1, retry step 2
                         const int bit = 4 * (kip >> 6) + eip;
@@ -672,7 +683,7 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                     }
                     R_norm = fmax(R_norm, rho);
                     const int off = tri(iq);
-                    const double irho = 1.0 / rho;
+                    STAMP(10);
                     if (lane < iq) {
                         W.R[off + lane] = da;
                         W.Rinv[lane * LDI + iq] = -ra * irho;
@@ -770,9 +781,12 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
                 if (oy) oy[(size_t)inst * N + kn[c]] = solved ? vy[c] : 0.0;
             }
     };
+    STAMP(12);
     respond(sd.Kx, sd.Wt, sd.Wp, out.jerk_x, out.jerk_y);
+    STAMP(13);
     respond(sd.Kc, sd.Sc, sd.Scp, out.com_x, out.com_y);
     respond(sd.Kv, sd.Sv, sd.Svp, out.com_xd, out.com_yd);
+    STAMP(14);
     if (out.zmp_x || out.zmp_y || out.min_margin) {
         // On a regular exit zx, zy were evaluated at the final multipliers in step 1.
         if (!zmp_current) {
@@ -802,7 +816,7 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
 #ifdef MPCB_STAMPS
     STAMP(8);
     if (lane == 0 && sd.dbg)
-        for (int i = 0; i < 10; i++) sd.dbg[(size_t)inst * 10 + i] = stamp_acc[i];
+        for (int i = 0; i < 16; i++) sd.dbg[(size_t)inst * 16 + i] = stamp_acc[i];
 #endif
 }
 

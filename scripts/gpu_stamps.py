@@ -4,7 +4,7 @@ os.environ["MPC_AMD_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mpc_amd import batches, planner as P
-names = ["prologue", "l1 rows", "s eval+psi", "select", "g gather", "d,r", "zn+t1", "step/add/drop", "epilogue", "-"]
+names = ["prologue", "l1 rows", "s eval+psi", "select", "g gather", "d,r", "zn+t1", "add writes (+drop)", "zmp/margin out", "t2,t", "f,u,rho", "-", "scalars/active out", "jerk out", "com,vel out", "-"]
 def run(wl, B):
     if wl == "coupled":
         bt = batches.coupled_batch(B)
@@ -14,7 +14,7 @@ def run(wl, B):
         bt = batches.decoupled_batch(B)
         pl = P.BatchedPlanner(100, formulation=P.BOX_1D, weight_R=1.0)
         prep = pl.prepare_box(bt["y0"], bt["ymin"], bt["ymax"]); call = lambda: pl.solve_box_prepared(prep)
-    dbg = torch.zeros((B, 10), dtype=torch.int64, device="cuda")
+    dbg = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
     lib = P.load_library()
     lib.mpcb_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
     lib.mpcb_debug_set_stamp_buffer(pl._h, dbg.data_ptr())
@@ -25,7 +25,7 @@ def run(wl, B):
     it = out["iters"].cpu().numpy()
     tot = d.sum(axis=1)
     print(wl, "B", B, "mean cycles/solve %.0f  mean iters %.1f" % (tot.mean(), it.mean()))
-    for i, n in enumerate(names[:9]):
+    for i, n in enumerate(names[:15]):
         print("  %-14s %9.0f cycles  %5.1f%%" % (n, d[:, i].mean(), 100 * d[:, i].sum() / tot.sum()))
 run("coupled", 8192)
 run("box", 4096)

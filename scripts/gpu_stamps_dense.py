@@ -8,7 +8,7 @@ B = 512
 bt = batches.decoupled_batch(B)
 pl = P.BatchedPlanner(100, formulation=P.BOX_1D, weight_R=1.0)
 prep = pl.prepare_box(bt["x0"], bt["xmin"], bt["xmax"])
-dbg = torch.zeros((B, 12), dtype=torch.int64, device="cuda")
+dbg = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
 lib = P.load_library()
 lib.mpcb_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
 lib.mpcb_debug_set_stamp_buffer(pl._h, dbg.data_ptr())
