@@ -296,6 +296,14 @@ def main():
         elapsed, dev_ms = tt[0].item(), tt[1].item()
 
     res = wl.results()
+    epilogue = None
+    if distributed:
+        # optional epilogue, outside the timed region: the only collective of the job
+        from mpc_amd import distributed as D
+        t_e = time.perf_counter()
+        best, where = D.best_cost(res["cost"], res["status"], rank * wl.B)
+        torch.cuda.synchronize()
+        epilogue = {"best_cost": best, "instance": where, "ms": (time.perf_counter() - t_e) * 1e3}
     status = res["status"].cpu().numpy()
     n_active = res["n_active"].cpu().numpy()
     iters = res["iters"].cpu().numpy()
@@ -345,6 +353,8 @@ def main():
                 "outer_iterations_mean": float(iters.mean()),
             },
         }
+        if epilogue is not None:
+            line["epilogue_best_cost"] = epilogue
         prof, prof_file = measured_profile(args.workload)
         if prof is not None:
             r = line["roofline"]

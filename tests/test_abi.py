@@ -78,6 +78,19 @@ idx = torch.arange(rank * B, (rank + 1) * B)
 gathered = [torch.zeros_like(idx) for _ in range(world)]
 dist.all_gather(gathered, idx)
 assert torch.cat(gathered).tolist() == list(range(B * world))
+# optional epilogue: gather of {cost, status} and best-cost selection, uneven split (7 over 2)
+from mpc_amd import distributed as D
+total = 7
+first, last = D.shard_bounds(total, rank, world)
+assert (first, last) == ((0, 4) if rank == 0 else (4, 7))
+all_cost = torch.tensor([5.0, 3.0, 9.0, 1.0, 0.5, 3.0, 0.25], dtype=torch.float64)
+all_stat = torch.tensor([0, 0, 0, 1, 0, 0, 1], dtype=torch.int32)  # instances 3 and 6 failed
+c, st = D.gather_cost_status(all_cost[first:last], all_stat[first:last])
+assert torch.equal(c, all_cost) and torch.equal(st, all_stat)
+best, where = D.best_cost(all_cost[first:last], all_stat[first:last], first)
+assert (best, where) == (0.5, 4), (best, where)
+best, where = D.best_cost(all_cost[first:last], torch.ones(last - first, dtype=torch.int32), first)
+assert where == -1
 dist.destroy_process_group()
 """ % ROOT
 
