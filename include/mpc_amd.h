@@ -36,7 +36,8 @@ enum {
     MPCB_COUPLED_JERK = 1, /* MPCPlanner::solveQPConstraintCoupled, 7-arg (MPCPlanner.cpp:427-490) */
     MPCB_COUPLED_VEL  = 2, /* MPCPlanner::solveQPConstraintCoupled, 9-arg (MPCPlanner.cpp:493-628) */
     MPCB_COUPLED_REF  = 3, /* MPCPlanner::solveQPConstraintCoupledRef     (MPCPlanner.cpp:632-783) */
-    MPCB_UNCONSTRAINED = 4 /* MPCPlanner::solveQP                         (MPCPlanner.cpp:223-237) */
+    MPCB_UNCONSTRAINED = 4,/* MPCPlanner::solveQP                         (MPCPlanner.cpp:223-237) */
+    MPCB_BOX_SLACK    = 5  /* MPCPlanner::solveQPconstraintSlack          (MPCPlanner.cpp:303-424) */
 };
 
 enum { MPCB_MODE_AUTO = 0, MPCB_MODE_DENSE = 1 };
@@ -68,7 +69,7 @@ typedef struct {
     double  height;             /* actual_height                                   */
     double  weight_R;           /* jerk weight                                     */
     double  weight_Q;           /* velocity weight                                 */
-    double  weight_Qs;          /* ZMP-reference weight (COUPLED_REF only)         */
+    double  weight_Qs;          /* ZMP-reference weight (COUPLED_REF), slack weight (BOX_SLACK) */
     int32_t replanning_window;  /* 1000 = constant velocity weights (MPCPlanner.cpp:535);
                                    otherwise Gaussian weights, makeGaussian (:1161-1171) */
     int32_t number_of_steps;    /* computeSteps' number_of_steps (coupled only)    */
@@ -125,6 +126,8 @@ typedef struct {
                                           dual active-set method (eiquadprog.hpp) spends along
                                           this instance's pivot sequence; used for roofline
                                           reporting, not a count of what the GPU executed      */
+    double  *slacks;            /* [B][2N] BOX_SLACK only: the slack variables (lower-bound
+                                          rows first), the `slacks` member of MPCPlanner.h:191 */
 } mpcb_outputs;
 
 /* Builds every instance-independent matrix (prediction matrices, condensed
@@ -173,7 +176,11 @@ int  mpcb_replan_sweep_device(mpcb_handle h, int32_t B, int32_t n_stages, int32_
 
 /* 1-D box-constrained plan: solveQPconstraint for B instances (one axis each).
  * x0 [B][3], zmin/zmax [B][N] (BoxLimits, MPCPlanner.h:29-34).  Outputs: the *_x
- * members; active_idx < N is the lower bound of that knot, >= N the upper bound. */
+ * members; active_idx < N is the lower bound of that knot, >= N the upper bound.
+ * With a BOX_SLACK handle the same call is solveQPconstraintSlack: 3N variables (jerk and
+ * one slack per bound), 4N rows (active_idx >= 2N: the sign constraint of slack
+ * active_idx - 2N); the working set holds about 2N rows, so give active_stride >= 4N to
+ * receive all of it; min_margin is the distance of the ZMP to the nearer bound. */
 int  mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const double *zmin,
                            const double *zmax, const mpcb_outputs *out, void *stream);
 int  mpcb_solve_box(mpcb_handle h, int32_t B, const double *x0, const double *zmin,

@@ -152,6 +152,25 @@ class MPCPlanner {
         check(mpcb_solve_box(h, 1, x0.data(), zmpLim.min.data(), zmpLim.max.data(), &o));
         finish(o);
     }
+    // :303-424: one slack variable per bound (weight_Qs), kept in `slacks` like the
+    // reference's member of that name (MPCPlanner.h:191)
+    void solveQPconstraintSlack(const double actual_height, const Vector3d &x0, const BoxLimits &zmpLim,
+                                VectorXd &jerk) {
+        need((int)zmpLim.min.size() == horizon_size_ && (int)zmpLim.max.size() == horizon_size_,
+             "box limits must have horizon_size entries");
+        last_height_ = actual_height;
+        mpcb_handle h = handle(MPCB_BOX_SLACK, actual_height, 1000, 1);
+        jerk.assign(horizon_size_, 0.0);
+        slacks.assign(2 * horizon_size_, 0.0);
+        mpcb_outputs o = outputs(jerk.data(), nullptr);
+        last_active_.assign(4 * horizon_size_, -1);
+        o.active_idx = last_active_.data();
+        o.active_stride = (int)last_active_.size();
+        o.slacks = slacks.data();
+        check(mpcb_solve_box(h, 1, x0.data(), zmpLim.min.data(), zmpLim.max.data(), &o));
+        finish(o);
+    }
+    VectorXd slacks;
     // :427-490
     void solveQPConstraintCoupled(const double actual_height, const Vector3d &x0, const Vector3d &y0,
                                   const MatrixXd &A, const VectorXd &b, VectorXd &jerk_x, VectorXd &jerk_y) {

@@ -104,7 +104,7 @@ int stage_outputs(Staging &st, const mpcb_outputs &h, mpcb_outputs &d, size_t B,
     OUT_(com_xd, B * N) OUT_(com_yd, B * N) OUT_(zmp_x, B * N) OUT_(zmp_y, B * N)
     OUT_(min_margin, B * N) OUT_(cost, B) OUT_(status, B) OUT_(iters, B) OUT_(n_active, B)
     OUT_(active_idx, B * (size_t)h.active_stride) OUT_(multipliers, B * (size_t)h.active_stride)
-    OUT_(alg_flops, B)
+    OUT_(alg_flops, B) OUT_(slacks, B * 2 * N)
 #undef OUT_
     return 0;
 }
@@ -117,7 +117,7 @@ int fetch_outputs(const mpcb_outputs &h, const mpcb_outputs &d, size_t B, size_t
     BACK_(com_xd, B * N) BACK_(com_yd, B * N) BACK_(zmp_x, B * N) BACK_(zmp_y, B * N)
     BACK_(min_margin, B * N) BACK_(cost, B) BACK_(status, B) BACK_(iters, B) BACK_(n_active, B)
     BACK_(active_idx, B * (size_t)h.active_stride) BACK_(multipliers, B * (size_t)h.active_stride)
-    BACK_(alg_flops, B)
+    BACK_(alg_flops, B) BACK_(slacks, B * 2 * N)
 #undef BACK_
     return 0;
 }
@@ -161,11 +161,14 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
     ds.N = hs.N;
     ds.m = hs.m;
     ds.axes = hs.axes;
+    ds.nvar = hs.nvar;
+    ds.slack_ls = hs.slack_ls;
+    ds.slack_g0 = hs.slack_g0;
     ds.form = params->formulation;
     ds.steps = hs.steps;
     ds.phase_knots = hs.phase_knots;
     ds.nphase = hs.nphase;
-    const int n = hs.N * hs.axes;
+    const int n = hs.nvar;
     ds.iter_cap = params->iter_cap > 0 ? params->iter_cap : 50 * (n + hs.m);
     std::memcpy(ds.F, hs.F, sizeof(ds.F));
     ds.psi_thr = (double)hs.m * 2.220446049250313e-16 * hs.c1 * hs.c2 * 100.0;
@@ -220,7 +223,7 @@ int ensure_workspace(mpcb_handle h, int B) {
     // are handled by the kernel's loop over the list
     const int want = B < 512 ? B : 512;
     if (want > h->dense_blocks) {
-        const size_t n = (size_t)h->hs.N * h->hs.axes;
+        const size_t n = (size_t)h->hs.nvar;
         double *J = nullptr, *R = nullptr;
         HIP_TRY(hipMalloc((void **)&J, (size_t)want * n * n * sizeof(double)));
         h->dev_allocs.push_back(J);
@@ -238,7 +241,8 @@ int solve_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &ou
     if (B == 0) return 0;
     int rc = ensure_workspace(h, B);
     if (rc) return rc;
-    if (h->params.solver_mode == MPCB_MODE_DENSE) {
+    // the slack formulation keeps about 2N rows active: beyond the first stage's capacity
+    if (h->params.solver_mode == MPCB_MODE_DENSE || h->params.formulation == MPCB_BOX_SLACK) {
         HIP_TRY(mpcb::launch_list_all(h->ws, B, stream));
     } else {
         HIP_TRY(hipMemsetAsync(h->ws.count, 0, sizeof(int), stream));
@@ -383,7 +387,8 @@ int mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const doub
     if (!h || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
     if (B == 0) return 0;
     if (!x0 || !zmin || !zmax) return fail(MPCB_E_ARG, "null input array");
-    if (h->params.formulation != MPCB_BOX_1D) return fail(MPCB_E_ARG, "handle was not created for BOX_1D");
+    if (h->params.formulation != MPCB_BOX_1D && h->params.formulation != MPCB_BOX_SLACK)
+        return fail(MPCB_E_ARG, "handle was not created for BOX_1D or BOX_SLACK");
     if ((out->active_idx || out->multipliers) && out->active_stride <= 0)
         return fail(MPCB_E_ARG, "active_stride must be positive");
     DeviceGuard guard(h->params.device);

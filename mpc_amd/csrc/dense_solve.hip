@@ -71,11 +71,16 @@ __device__ __forceinline__ void block_argmin(double &val, int &key, double *red,
 
 // LDSJ: J (n x n) and R (packed, one sub-diagonal) live in the workgroup's LDS instead of
 // its HBM workspace slot -- possible up to n ~ 105, e.g. the N = 100 box problems.
-template <bool POLY, bool LDSJ>
+// FORM: 0 = box rows on one axis (solveQPconstraint), 1 = polygon rows on both axes
+// (solveQPConstraintCoupled*), 2 = box rows with one slack variable per bound
+// (solveQPconstraintSlack, MPCPlanner.cpp:351-394: x = [jerk; slacks], G = diag(R I, Qs I),
+// g0 = [0; 1000 Qs], rows i < 2N: -/+ (zmp_k - bound) + slack_i >= 0, rows 2N + i: -slack_i >= 0).
+template <int FORM, bool LDSJ>
 __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_outputs out, DenseWs ws) {
+    constexpr bool POLY = FORM == 1, SLACK = FORM == 2;
     extern __shared__ double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = sd.N, n = POLY ? 2 * N : N, m = sd.m;
+    const int N = sd.N, n = POLY ? 2 * N : SLACK ? 3 * N : N, m = sd.m;
     // ---- LDS carve-up -------------------------------------------------------
     double *x = smem, *z = x + n, *d = z + n, *np = d + n, *x_old = np + n;
     double *u = x_old + n, *u_old = u + (n + 1), *r = u_old + (n + 1);
@@ -181,16 +186,20 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                 zy[k] = ay;
             }
             __syncthreads();
-            if (only >= 0) {
-                if (tid == 0) {
-                    const int k = rowK(only);
-                    s[only] = rowP(only, k) * zx[k] + rowQ(only, k) * zy[k] + rowR(only, k);
-                }
-            } else {
-                for (int i = tid; i < m; i += T) {
+            auto row_value = [&](int i) -> double {
+                if constexpr (SLACK) {
+                    if (i >= 2 * N) return -x[N + (i - 2 * N)];
+                    const int k = i < N ? i : i - N;
+                    return (i < N ? zx[k] - lo[k] : hi[k] - zx[k]) + x[N + i];
+                } else {
                     const int k = rowK(i);
-                    s[i] = rowP(i, k) * zx[k] + rowQ(i, k) * zy[k] + rowR(i, k);
+                    return rowP(i, k) * zx[k] + rowQ(i, k) * zy[k] + rowR(i, k);
                 }
+            };
+            if (only >= 0) {
+                if (tid == 0) s[only] = row_value(only);
+            } else {
+                for (int i = tid; i < m; i += T) s[i] = row_value(i);
             }
             __syncthreads();
         };
@@ -201,10 +210,17 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             for (int row = tid; row < n; row += T) {
                 double v = 0.0;
                 if (col < N && row < N) v = ws.J1[(size_t)col * N + row];
-                else if (col >= N && row >= N) v = ws.J1[(size_t)(col - N) * N + (row - N)];
+                else if (SLACK && col >= N && row == col) v = 1.0 / sd.slack_ls;
+                else if (POLY && col >= N && row >= N) v = ws.J1[(size_t)(col - N) * N + (row - N)];
                 J[(size_t)col * ldj + row] = v;
             }
+        // slack part of x = -G^-1 g0 through the factor, as chol.solve does (eiquadprog.hpp:188)
+        const double slack_x0 = -((sd.slack_g0 / sd.slack_ls) / sd.slack_ls);
         for (int i = tid; i < n; i += T) {
+            if (SLACK && i >= N) {
+                x[i] = slack_x0;
+                continue;
+            }
             const int k = i < N ? i : i - N;
             const double *kx = sd.Kx + (size_t)k * 4;
             const double *w = i < N ? wx : wy;
@@ -223,6 +239,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                 fp += unconstrained_cost_part(sd, wx, cref, 0, pb + tid, pb + tid == 0) +
                       unconstrained_cost_part(sd, wy, cref, 1, pb + tid, pb + tid == 0);
             f = block_sum(fp, red, tid);
+            if constexpr (SLACK) f += 0.5 * (2.0 * N) * sd.slack_g0 * slack_x0; // 1/2 g0'x (:191)
         }
         for (int i = tid; i < m; i += T) iai[i] = i;
         double R_norm = 1.0;
@@ -445,7 +462,20 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     break;
                 }
                 // np = CI.col(ip)
-                {
+                if constexpr (SLACK) {
+                    const int k = ip < N ? ip : ip - N;
+                    const double p = ip < N ? 1.0 : -1.0;
+                    for (int j = tid; j < n; j += T) {
+                        double v = 0.0;
+                        if (ip < 2 * N) {
+                            if (j < N) v = j <= k ? p * zc[k - j] : 0.0;
+                            else v = j == N + ip ? 1.0 : 0.0;
+                        } else {
+                            v = j == N + (ip - 2 * N) ? -1.0 : 0.0;
+                        }
+                        np[j] = v;
+                    }
+                } else {
                     const int k = rowK(ip);
                     const double p = rowP(ip, k), q = rowQ(ip, k);
                     for (int j = tid; j < N; j += T) {
@@ -736,6 +766,10 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             for (int i = tid; i < n; i += T) x[i] = 0.0;
         __syncthreads();
         eval_s(-1);
+        if constexpr (SLACK) {
+            if (out.slacks)
+                for (int i = tid; i < 2 * N; i += T) out.slacks[(size_t)inst * 2 * N + i] = x[N + i];
+        }
         for (int k = tid; k < N; k += T) {
             const size_t o = (size_t)inst * N + k;
             if (out.jerk_x) out.jerk_x[o] = x[k];
@@ -773,6 +807,8 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     const int ph = sd.knot_phase[k];
                     const int E = ((ph & 1) && ph < 2 * sd.steps) ? 3 : 4;
                     for (int e = 0; e < E; e++) mn = fmin(mn, s[r0 + e]);
+                } else if constexpr (SLACK) {
+                    mn = fmin(zx[k] - lo[k], hi[k] - zx[k]);
                 } else {
                     mn = fmin(s[k], s[N + k]);
                 }
@@ -790,7 +826,7 @@ __global__ void list_all_kernel(int *list, int *count, int B) {
 }
 
 size_t dense_lds_bytes(const DevSetup &sd, bool ldsj) {
-    const size_t N = sd.N, n = sd.axes * N, m = sd.m;
+    const size_t N = sd.N, n = sd.nvar, m = sd.m;
     size_t doubles = 5 * n + 3 * (n + 1) + 3 * n + (n + 1) + m + 5 * N + (size_t)sd.nphase * 14 + 4;
     size_t ints = 4 + 2 * (n + 1) + 2 * m;
     size_t bytes = doubles * 8 + ints * 4 + 64;
@@ -813,10 +849,13 @@ hipError_t launch_dense(const DevSetup &sd, const DevIn &in, const mpcb_outputs 
     const bool ldsj = dense_lds_bytes(sd, true) <= 160 * 1024 - 256;
     const size_t shmem = dense_lds_bytes(sd, ldsj);
     const void *fn;
-    if (poly) fn = ldsj ? reinterpret_cast<const void *>(dense_kernel<true, true>)
-                        : reinterpret_cast<const void *>(dense_kernel<true, false>);
-    else fn = ldsj ? reinterpret_cast<const void *>(dense_kernel<false, true>)
-                   : reinterpret_cast<const void *>(dense_kernel<false, false>);
+    if (sd.form == MPCB_BOX_SLACK)
+        fn = ldsj ? reinterpret_cast<const void *>(dense_kernel<2, true>)
+                  : reinterpret_cast<const void *>(dense_kernel<2, false>);
+    else if (poly) fn = ldsj ? reinterpret_cast<const void *>(dense_kernel<1, true>)
+                             : reinterpret_cast<const void *>(dense_kernel<1, false>);
+    else fn = ldsj ? reinterpret_cast<const void *>(dense_kernel<0, true>)
+                   : reinterpret_cast<const void *>(dense_kernel<0, false>);
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;

@@ -14,6 +14,8 @@ constexpr int STATUS_UNRESOLVED = 3;
 
 struct DevSetup {
     int N, m, axes, form;
+    int nvar;                         // variables of one QP (axes * N; 3N with slacks)
+    double slack_ls, slack_g0;        // BOX_SLACK: sqrt(Qs) and the linear cost 1000 * Qs
     int steps, phase_knots, nphase;
     int iter_cap;
     const double *S, *Wt, *Sc, *Sv;   // N x N response matrices, row k = knot k

@@ -136,7 +136,7 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
         return MPCB_E_ARG;
     }
     const int form = p.formulation;
-    if (form < MPCB_BOX_1D || form > MPCB_UNCONSTRAINED) {
+    if (form < MPCB_BOX_1D || form > MPCB_BOX_SLACK) {
         *err = "unknown formulation";
         return MPCB_E_ARG;
     }
@@ -144,6 +144,11 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
     o = HostSetup();
     o.N = N;
     o.axes = coupled ? 2 : 1;
+    o.nvar = form == MPCB_BOX_SLACK ? 3 * N : o.axes * N;
+    if (form == MPCB_BOX_SLACK && !(p.weight_Qs > 0)) {
+        *err = "weight_Qs must be positive for BOX_SLACK";
+        return MPCB_E_ARG;
+    }
 
     const ld Ts = p.Ts;
     const ld Cz[3] = {1, 0, -(ld)p.height / (ld)p.gravity};
@@ -219,6 +224,13 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
     for (int i = 0; i < N; i++) trJ += 1 / L[(size_t)i * N + i];
     o.c1 = (double)(tr * o.axes);
     o.c2 = (double)(trJ * o.axes);
+    if (form == MPCB_BOX_SLACK) {
+        // G = diag(R I_N, Qs I_2N) (MPCPlanner.cpp:368-370): traces of G and of L^-T
+        o.slack_ls = sqrt(p.weight_Qs);
+        o.slack_g0 = 1000 * p.weight_Qs; // :373
+        o.c1 = (double)(tr + 2 * (ld)N * (ld)p.weight_Qs);
+        o.c2 = (double)(trJ + 2 * (ld)N / sqrtl((ld)p.weight_Qs));
+    }
 
     // W = G1^-1 Zu^T  (N x N), then the response matrices
     LVec W = ZuT;
@@ -354,7 +366,7 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
             o.F3 = to_double(F3);
         }
     } else {
-        o.m = (form == MPCB_BOX_1D) ? 2 * N : 0;
+        o.m = (form == MPCB_BOX_1D) ? 2 * N : (form == MPCB_BOX_SLACK) ? 4 * N : 0;
         o.nphase = 0;
         for (int k = 0; k < N; k++) o.knot_row0[k] = k;
     }

@@ -13,6 +13,8 @@ struct HostSetup {
     int N = 0;            // horizon
     int m = 0;            // inequality rows per instance
     int axes = 2;         // 1 for BOX_1D
+    int nvar = 0;         // variables of one QP: axes * N, or 3N with one slack per bound
+    double slack_ls = 0, slack_g0 = 0; // BOX_SLACK: sqrt(Qs), 1000 * Qs
     int steps = 0, phase_knots = 0, nphase = 0;
     // N x N, row k = response to a unit (multiplier * coefficient) at knot k
     std::vector<double> S;    // ZMP           S  = Zu  G1^-1 Zu^T   (symmetric)

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPC_AMD_LIB selects another build of the same library (e.g. the cycle-stamp build)
 LIB_PATH = os.environ.get("MPC_AMD_LIB") or os.path.join(_HERE, "libmpc_amd.so")
 
-BOX_1D, COUPLED_JERK, COUPLED_VEL, COUPLED_REF, UNCONSTRAINED = 0, 1, 2, 3, 4
+BOX_1D, COUPLED_JERK, COUPLED_VEL, COUPLED_REF, UNCONSTRAINED, BOX_SLACK = 0, 1, 2, 3, 4, 5
 OK, INFEASIBLE, ITER_CAP = 0, 1, 2
 MODE_AUTO, MODE_DENSE = 0, 1
 
@@ -53,7 +53,7 @@ _OUT_I32 = ("status", "iters", "n_active", "active_idx")
 class Outputs(C.Structure):
     _fields_ = ([(k, C.c_void_p) for k in _OUT_F64] + [(k, C.c_void_p) for k in _OUT_I32] +
                 [("multipliers", C.c_void_p), ("active_stride", C.c_int32),
-                 ("alg_flops", C.c_void_p)])
+                 ("alg_flops", C.c_void_p), ("slacks", C.c_void_p)])
 
 
 _lib = None
@@ -97,6 +97,7 @@ def _check(rc):
 
 
 ALL_OUTPUTS = _OUT_F64 + _OUT_I32 + ("multipliers", "alg_flops")
+SLACK_OUTPUTS = ALL_OUTPUTS + ("slacks",)  # BOX_SLACK handles
 DEFAULT_OUTPUTS = ALL_OUTPUTS
 
 
@@ -161,10 +162,12 @@ class BatchedPlanner:
         N = self.horizon
         res, o = {}, Outputs()
         o.active_stride = self.active_stride
-        for name in ALL_OUTPUTS:
+        for name in SLACK_OUTPUTS:
             if name not in outputs:
                 continue
-            if name in ("cost", "alg_flops"):
+            if name == "slacks":
+                t = torch.empty((B, 2 * N), dtype=torch.float64, device=self.device)
+            elif name in ("cost", "alg_flops"):
                 t = torch.empty(B, dtype=torch.float64, device=self.device)
             elif name in ("status", "iters", "n_active"):
                 t = torch.empty(B, dtype=torch.int32, device=self.device)

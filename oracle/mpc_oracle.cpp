@@ -706,6 +706,42 @@ struct Planner {
         return solve_quadprog(GQ, g0, CIt, ci0, jerk, info, active, iter_cap);
     }
 
+    /* solveQPconstraintSlack, :303-424 (the live "one slack per constraint" version,
+       :351-394): x = [jerk (N); slacks (2N)], G = diag(R I, Qs I), g0 = [0; 1000 Qs],
+       rows 0..2N-1  (+/-Zu jerk + slack_i + ci0_i >= 0), rows 2N..4N-1 (-slack_i >= 0).
+       `sol` receives all 3N variables. */
+    double solveQPconstraintSlack(double h, const double x0[3], const Vec &zmin, const Vec &zmax,
+                                  Vec &sol, orc_info *info, int *active) {
+        setHeight(h);
+        Mat Zx, Zu;
+        buildMatrix(Cz, Zx, Zu, N);
+        const int ns = 2 * N, n = N + ns, m = 2 * N + ns;
+        Mat GQ(n, n);
+        for (int i = 0; i < N; i++) GQ(i, i) = R;
+        for (int i = N; i < n; i++) GQ(i, i) = Qs;
+        Vec g0(n, 0.0);
+        for (int i = N; i < n; i++) g0[i] = 1000 * Qs;
+        Mat CI(m, n);
+        Vec ci0(m, 0.0);
+        Vec x0v(x0, x0 + 3);
+        Vec zx0 = matvec(Zx, x0v);
+        for (int j = 0; j < N; j++)
+            for (int i = 0; i < N; i++) {
+                CI(i, j) = Zu(i, j);
+                CI(N + i, j) = -Zu(i, j);
+            }
+        for (int i = 0; i < N; i++) {
+            ci0[i] = zx0[i] - zmin[i];
+            ci0[N + i] = zmax[i] - zx0[i];
+        }
+        for (int i = 0; i < ns; i++) {
+            CI(i, N + i) = 1.0;
+            CI(2 * N + i, N + i) = -1.0;
+        }
+        Mat CIt = transpose(CI);
+        return solve_quadprog(GQ, g0, CIt, ci0, sol, info, active, iter_cap);
+    }
+
     /* velocity block shared by :531-571 and :672-712 */
     void velocityTerms(const double x0[3], const double y0[3], const double speed[2], int rw,
                        Mat &Gv1, Vec &gvx, Vec &gvy) {
@@ -1391,6 +1427,35 @@ int orc_box_batch(const orc_params *p, int B, const double *x0, const double *y0
                     for (int k = 0; k < active_stride; k++)
                         active[o * active_stride + k] = (k < li.n_active) ? act[k] : -1;
             }
+        }
+    });
+    return 0;
+}
+
+/* solveQPconstraintSlack for B instances of one axis.  sol: [B][3N] (jerk, then the 2N
+   slacks); active: [B][active_stride]. */
+int orc_slack_batch(const orc_params *p, int B, const double *x0, const double *zmin,
+                    const double *zmax, double *sol, double *cost, int *status, int *n_active,
+                    int *active, int active_stride, int *iters, double *falg, int nthreads) {
+    const int N = p->N;
+    parallel_for(B, nthreads, [&](int lo, int hi, int) {
+        Planner pl = make_planner(p);
+        std::vector<int> act(4 * N + 1);
+        for (int i = lo; i < hi; i++) {
+            const double *mn = zmin + (size_t)i * N, *mx = zmax + (size_t)i * N;
+            Vec lo_(mn, mn + N), hi_(mx, mx + N), x;
+            orc_info li;
+            pl.solveQPconstraintSlack(p->height, x0 + 3 * (size_t)i, lo_, hi_, x, &li, act.data());
+            if (li.status != ORC_OK) std::fill(x.begin(), x.end(), 0.0);
+            if (sol) std::copy(x.begin(), x.end(), sol + (size_t)i * 3 * N);
+            if (cost) cost[i] = li.f;
+            if (status) status[i] = li.status;
+            if (n_active) n_active[i] = li.n_active;
+            if (iters) iters[i] = li.iters;
+            if (falg) falg[i] = li.falg;
+            if (active)
+                for (int k = 0; k < active_stride; k++)
+                    active[(size_t)i * active_stride + k] = (k < li.n_active) ? act[k] : -1;
         }
     });
     return 0;

@@ -165,6 +165,13 @@ int orc_box_batch(const orc_params *p, int B, const double *x0, const double *y0
                   int *n_active /* [B][2] */, int *active /* [B][2][stride] */,
                   int active_stride, int *iters, double *falg, int nthreads);
 
+/* solveQPconstraintSlack (MPCPlanner.cpp:303-424) for B instances of one axis.
+   sol: [B][3N] = jerk (N) then slacks (2N); active rows: 0..N-1 lower bound,
+   N..2N-1 upper bound, 2N..4N-1 slack sign. */
+int orc_slack_batch(const orc_params *p, int B, const double *x0, const double *zmin,
+                    const double *zmax, double *sol, double *cost, int *status, int *n_active,
+                    int *active, int active_stride, int *iters, double *falg, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

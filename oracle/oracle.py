@@ -234,6 +234,22 @@ def box_batch(p, x0, y0, xmin, xmax, ymin, ymax, active_stride=64, nthreads=1):
     return out
 
 
+def slack_batch(p, x0, zmin, zmax, active_stride=512, nthreads=1):
+    """solveQPconstraintSlack (MPCPlanner.cpp:303-424) for a batch of one-axis instances.
+    sol[:, :N] is the jerk, sol[:, N:] the 2N slacks."""
+    x0, zmin, zmax = map(_d, (x0, zmin, zmax))
+    B, N = x0.shape[0], p.N
+    out = dict(sol=np.zeros((B, 3 * N)), cost=np.zeros(B), status=np.zeros(B, dtype=np.int32),
+               n_active=np.zeros(B, dtype=np.int32), active=np.zeros((B, active_stride), dtype=np.int32),
+               iters=np.zeros(B, dtype=np.int32), falg=np.zeros(B))
+    lib().orc_slack_batch(C.byref(p), B, _p(x0), _p(zmin), _p(zmax), _p(out["sol"]), _p(out["cost"]),
+                          _p(out["status"]), _p(out["n_active"]), _p(out["active"]), active_stride,
+                          _p(out["iters"]), _p(out["falg"]), nthreads)
+    out["jerk"] = out["sol"][:, :N]
+    out["slacks"] = out["sol"][:, N:]
+    return out
+
+
 def replanning_batch(p, steps, n_stages, x0, y0, speed, feet_x, feet_y, swing0, disturbance,
                      disturbance_start=4, use_com_correction=True, hip=None, nthreads=1):
     """The replanning driver's loop for a batch of rollouts.  Returns the evolved state

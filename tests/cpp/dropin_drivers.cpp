@@ -6,6 +6,7 @@
 // Each writes the same "time value" text files into $HOME through saveTraj and prints a
 // few values as key=value lines for the test that runs it.
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 
 #include "mpc_amd_planner.hpp"
@@ -70,7 +71,7 @@ static int coupled() {
     return 0;
 }
 
-static int decoupled() {
+static int decoupled(bool useSlacks) {
     int horizon_size = 100, number_of_steps = 10;
     double distance = 3.0, height = 0.5, lateral_bound = 0.2, Ts = 0.1, weight_R = 1, weight_Q = 1;
     VectorXd jerk_x, jerk_y, zmp_x, zmp_y, com_x, com_y;
@@ -113,10 +114,21 @@ static int decoupled() {
     fill(zmpLimX.min, start, missing, low - distance_per_step * overlap);
     fill(zmpLimY.max, start, missing, 1.0);
     fill(zmpLimY.min, start, missing, -1.0);
-    myPlanner.solveQPconstraint(height, initial_state_x, zmpLimX, jerk_x);
-    const int nx = (int)myPlanner.lastActiveSet().size();
-    myPlanner.solveQPconstraint(height, initial_state_y, zmpLimY, jerk_y);
-    const int ny = (int)myPlanner.lastActiveSet().size();
+    int nx, ny;
+    if (!useSlacks) {
+        myPlanner.solveQPconstraint(height, initial_state_x, zmpLimX, jerk_x);
+        nx = (int)myPlanner.lastActiveSet().size();
+        myPlanner.solveQPconstraint(height, initial_state_y, zmpLimY, jerk_y);
+        ny = (int)myPlanner.lastActiveSet().size();
+    } else { // testPlannerXYconstraintDecoupled.cpp:130-137
+        weight_R = 1e-06;
+        double weight_Qs = 1;
+        myPlanner.setWeights(weight_R, weight_Q, weight_Qs);
+        myPlanner.solveQPconstraintSlack(height, initial_state_x, zmpLimX, jerk_x);
+        nx = (int)myPlanner.lastActiveSet().size();
+        myPlanner.solveQPconstraintSlack(height, initial_state_y, zmpLimY, jerk_y);
+        ny = (int)myPlanner.lastActiveSet().size();
+    }
     myPlanner.computeZMPtrajectory(initial_state_x, jerk_x, zmp_x);
     myPlanner.computeZMPtrajectory(initial_state_y, jerk_y, zmp_y);
     myPlanner.computeCOMtrajectory(initial_state_x, jerk_x, com_x);
@@ -127,8 +139,11 @@ static int decoupled() {
     myPlanner.saveTraj("zmp_y.txt", zmp_y);
     myPlanner.saveTraj("min_y.txt", zmpLimY.min);
     myPlanner.saveTraj("max_y.txt", zmpLimY.max);
-    std::printf("jerk_y0=%.9g\njerk_y1=%.9g\njerk_y2=%.9g\nx_active=%d\ny_active=%d\n", jerk_y[0], jerk_y[1],
-                jerk_y[2], nx, ny);
+    double margin_y = 1e300; // distance of the Y ZMP to its nearer bound, minimum over the horizon
+    for (int k = 0; k < horizon_size; k++)
+        margin_y = std::min(margin_y, std::min(zmp_y[k] - zmpLimY.min[k], zmpLimY.max[k] - zmp_y[k]));
+    std::printf("jerk_y0=%.9g\njerk_y1=%.9g\njerk_y2=%.9g\nx_active=%d\ny_active=%d\nmargin_y=%.9g\n", jerk_y[0],
+                jerk_y[1], jerk_y[2], nx, ny, margin_y);
     return 0;
 }
 
@@ -154,12 +169,13 @@ static int qp() {
 int main(int argc, char **argv) {
     try {
         if (argc > 1 && !std::strcmp(argv[1], "coupled")) return coupled();
-        if (argc > 1 && !std::strcmp(argv[1], "decoupled")) return decoupled();
+        if (argc > 1 && !std::strcmp(argv[1], "decoupled")) return decoupled(false);
+        if (argc > 1 && !std::strcmp(argv[1], "decoupled_slack")) return decoupled(true);
         if (argc > 1 && !std::strcmp(argv[1], "qp")) return qp();
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 2;
     }
-    std::fprintf(stderr, "usage: %s coupled|decoupled|qp\n", argv[0]);
+    std::fprintf(stderr, "usage: %s coupled|decoupled|decoupled_slack|qp\n", argv[0]);
     return 1;
 }

@@ -114,6 +114,32 @@ def test_box_vs_oracle(P, oracle):
             assert np.isinf(o["cost"][bad]).all() and (o["jerk_x"][bad] == 0).all()
 
 
+@pytest.mark.parametrize("N,R,Qs", [(100, 1.0, 100.0), (40, 0.5, 10.0)])
+def test_box_slack_variant_vs_oracle(P, oracle, N, R, Qs):
+    """solveQPconstraintSlack (MPCPlanner.cpp:303-424): 3N variables, 4N rows, about 2N of them
+    active.  No output of the reference is recorded for this variant, so the only anchor is the
+    CPU restatement (parity unpinned)."""
+    B = 12
+    bb = batches.decoupled_batch(B, N=N, steps=10)
+    pl = P.BatchedPlanner(N, formulation=P.BOX_SLACK, weight_R=R, weight_Qs=Qs, active_stride=4 * N)
+    o = _np(pl.solve_box(bb["y0"], bb["ymin"], bb["ymax"], outputs=P.SLACK_OUTPUTS))
+    ref = oracle.slack_batch(oracle.params(N, R=R, Qs=Qs, height=0.5, iter_cap=50 * 7 * N), bb["y0"],
+                             bb["ymin"], bb["ymax"], active_stride=4 * N, nthreads=16)
+    assert (o["status"] == ref["status"]).all()
+    assert (o["iters"] == ref["iters"]).all()
+    for i in range(B):
+        na = ref["n_active"][i]
+        assert o["n_active"][i] == na
+        assert list(o["active_idx"][i, :na]) == list(ref["active"][i, :na])
+        assert _rel(o["jerk_x"][i], ref["jerk"][i]) < RTOL
+        assert _rel(o["slacks"][i], ref["slacks"][i]) < RTOL
+    assert (np.abs(o["cost"] - ref["cost"]) <= RTOL * np.abs(ref["cost"])).all()
+    assert np.allclose(o["alg_flops"], ref["falg"], rtol=1e-12)
+    # the slacks are the (negated) distances of the ZMP to its bounds wherever a bound row is active
+    assert (o["slacks"] <= 1e-9).all()
+    assert np.allclose(o["min_margin"], np.minimum(o["zmp_x"] - bb["ymin"], bb["ymax"] - o["zmp_x"]))
+
+
 def test_default_driver_scenarios(P):
     """The recorded outputs of the reference's two default drivers, through the GPU path."""
     import json, os
@@ -359,5 +385,10 @@ def test_cpp_dropin_drivers(P, tmp_path):
     g = gold["decoupled_default"]
     assert np.allclose([d["jerk_y0"], d["jerk_y1"], d["jerk_y2"]], g["jerk_y_0_2"], rtol=2e-6)
     assert d["y_active"] == sum(g["y_active_upper_lower"]) and d["x_active"] == sum(g["x_active_upper_lower"])
+    # the driver's other mode (use slacks = 1): the slacks keep the ZMP away from its bounds,
+    # where the plain box solve lets it touch them
+    ds = run("decoupled_slack")
+    assert d["margin_y"] < 1e-6 and ds["margin_y"] > 0.05
+    assert ds["y_active"] >= 200 and ds["x_active"] >= 200  # every bound row carries its slack
     q = run("qp")
     assert abs(q["zmp99"] - 0.2) < 1e-2  # the ZMP follows the linear reference

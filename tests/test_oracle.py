@@ -215,6 +215,39 @@ def test_quadprog_kkt_and_scipy(oracle):
         assert np.abs(res.x - x).max() < 1e-5
 
 
+def test_slack_variant_kkt_and_closed_form(oracle):
+    """solveQPconstraintSlack (MPCPlanner.cpp:303-424): KKT conditions of the 3N-variable QP, and
+    the closed form it reduces to while the ZMP stays inside its box -- every bound row active,
+    slack_i = -(distance to bound i), which leaves min R/2 |j|^2 + Qs sum (zmp - mid)^2 + const."""
+    from mpc_amd import batches
+    N, R, Qs = 30, 0.5, 10.0
+    bb = batches.decoupled_batch(4, N=N, steps=5)
+    p = oracle.params(N, R=R, Qs=Qs, height=0.5)
+    o = oracle.slack_batch(p, bb["y0"], bb["ymin"], bb["ymax"], active_stride=4 * N, nthreads=2)
+    Zx, Zu = oracle.build_matrix(p, 3)  # 3 = the ZMP output row Cz
+    G = np.diag([R] * N + [Qs] * (2 * N))
+    g0 = np.r_[np.zeros(N), 1000 * Qs * np.ones(2 * N)]
+    for i in range(4):
+        assert o["status"][i] == oracle.OK
+        zx0 = Zx @ bb["y0"][i]
+        CIt = np.zeros((4 * N, 3 * N))
+        CIt[:N, :N], CIt[N:2 * N, :N] = Zu, -Zu
+        CIt[:2 * N, N:] = np.eye(2 * N)
+        CIt[2 * N:, N:] = -np.eye(2 * N)
+        ci0 = np.r_[zx0 - bb["ymin"][i], bb["ymax"][i] - zx0, np.zeros(2 * N)]
+        x = o["sol"][i]
+        act = list(o["active"][i, :o["n_active"][i]])
+        s, u, resid = _kkt(G, g0, CIt.T, ci0, x, act)
+        assert s.min() > -1e-7 and np.abs(resid).max() < 1e-6 * np.abs(g0).max() and (u > -1e-6).all()
+        assert o["cost"][i] == pytest.approx(0.5 * x @ G @ x + g0 @ x, rel=1e-10)
+        zmp = zx0 + Zu @ x[:N]
+        inside = (zmp > bb["ymin"][i]).all() and (zmp < bb["ymax"][i]).all()
+        if inside and set(range(2 * N)) <= set(act) and len(act) == 2 * N:
+            mid = 0.5 * (bb["ymin"][i] + bb["ymax"][i])
+            j = np.linalg.solve(R * np.eye(N) + 2 * Qs * Zu.T @ Zu, -2 * Qs * Zu.T @ (zx0 - mid))
+            assert np.abs(j - x[:N]).max() < 1e-7 * max(1.0, np.abs(j).max())
+
+
 def test_infeasible_and_empty(oracle):
     G = np.eye(2)
     # x >= 1 and x <= 0 on the same coordinate
