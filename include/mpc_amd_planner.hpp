@@ -51,6 +51,84 @@ struct MatrixXd {
     double operator()(int i, int j) const { return a[(size_t)j * r + i]; }
 };
 
+// The four-slot cyclic swing schedule of FootScheduler.h:15-99.
+class FootScheduler {
+  public:
+    FootScheduler() { setSequence(LF, RH, RF, LH); }
+    FootScheduler(LegID leg1, LegID leg2, LegID leg3, LegID leg4) { setSequence(leg1, leg2, leg3, leg4); }
+    void setSequence(LegID leg1, LegID leg2, LegID leg3, LegID leg4) {
+        seq_ = {leg1, leg2, leg3, leg4};
+        cur_ = 0;
+    }
+    LegID getCurrentSwing() const { return seq_[cur_]; }
+    void setCurrentSwing(LegID start) { // stays put if the leg is not in the sequence
+        for (int i = 0; i < 4; i++)
+            if (seq_[i] == start) {
+                cur_ = i;
+                break;
+            }
+    }
+    LegID getOppositeSwing() const {
+        switch (getCurrentSwing()) {
+        case LF: return RH;
+        case RF: return LH;
+        case LH: return RF;
+        default: return LF;
+        }
+    }
+    LegID getNextSwing() const { return seq_[(cur_ + 1) % 4]; }
+    LegID getPreviousSwing() const { return seq_[(cur_ + 3) % 4]; }
+    void next() { cur_ = (cur_ + 1) % 4; }
+
+  private:
+    std::array<LegID, 4> seq_;
+    int cur_ = 0;
+};
+
+// The planner-related keys of the reference's config/planner.ini: [Crawl] linearSpeedX,
+// linearSpeedY (the per-step displacement / velocity target handed to computeSteps and the
+// velocity formulation) and [Replanning] useComStepCorrection, optimizeVelocity (the two
+// switches of the replanning driver).  Unknown sections and keys are ignored, '#' starts a
+// comment, a missing file or key keeps the default.
+struct PlannerIni {
+    double linearSpeedX = 0.15, linearSpeedY = 0.0;
+    int useComStepCorrection = 1, optimizeVelocity = 1;
+    bool loaded = false;
+
+    static PlannerIni read(const std::string &path) {
+        PlannerIni ini;
+        std::ifstream f(path.c_str());
+        if (!f) return ini;
+        ini.loaded = true;
+        std::string line, section;
+        auto trim = [](std::string t) {
+            const char *ws = " \t\r\n";
+            const size_t a = t.find_first_not_of(ws);
+            if (a == std::string::npos) return std::string();
+            return t.substr(a, t.find_last_not_of(ws) - a + 1);
+        };
+        while (std::getline(f, line)) {
+            const size_t hash = line.find('#');
+            if (hash != std::string::npos) line.erase(hash);
+            line = trim(line);
+            if (line.empty()) continue;
+            if (line[0] == '[') {
+                section = trim(line.substr(1, line.find(']') == std::string::npos ? std::string::npos : line.find(']') - 1));
+                continue;
+            }
+            const size_t eq = line.find('=');
+            if (eq == std::string::npos) continue;
+            const std::string key = trim(line.substr(0, eq)), val = trim(line.substr(eq + 1));
+            if (val.empty()) continue;
+            if (section == "Crawl" && key == "linearSpeedX") ini.linearSpeedX = std::atof(val.c_str());
+            else if (section == "Crawl" && key == "linearSpeedY") ini.linearSpeedY = std::atof(val.c_str());
+            else if (section == "Replanning" && key == "useComStepCorrection") ini.useComStepCorrection = std::atoi(val.c_str());
+            else if (section == "Replanning" && key == "optimizeVelocity") ini.optimizeVelocity = std::atoi(val.c_str());
+        }
+        return ini;
+    }
+};
+
 class MPCPlanner {
   public:
     struct BoxLimits { // MPCPlanner.h:29-34
@@ -87,6 +165,10 @@ class MPCPlanner {
         weight_Qs_ = weight_Qs;
     }
     void setHorizonSize(int horizon) { horizon_size_ = horizon; } // :78-92
+    void printSwing(LegID swing) const { // :1331-1349
+        static const char *names[4] = {"LF", "RF", "LH", "RH"};
+        std::printf("swing %s:\n", names[(int)swing & 3]);
+    }
     void setHipOffsets(const LegDataMap<Vector2d> &hip_offsets) {  // :1352-1355
         for (int l = 0; l < 4; l++) {
             hip_offsets_[2 * l] = hip_offsets[l][0];

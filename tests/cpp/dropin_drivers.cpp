@@ -7,6 +7,7 @@
 // few values as key=value lines for the test that runs it.
 #include <cstdio>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "mpc_amd_planner.hpp"
@@ -166,16 +167,100 @@ static int qp() {
     return 0;
 }
 
+// tests/replanning/testPlannerXYconstraintMPC.cpp with its prompts' defaults, except where
+// argv overrides them: replanning <planner.ini or -> <disturbance> <experiment_duration>.
+// The ini file supplies userSpeed and the two switches.  Hip offsets are set explicitly (the
+// reference's driver leaves them uninitialised).
+static int replanning(const char *ini_path, double disturbance, int experiment_duration) {
+    int horizon_size = 200, number_of_steps = 20;
+    double height = 0.5, Ts = 0.1, weight_R = 1e-06, weight_Q = 1;
+    VectorXd jerk_x, jerk_y;
+    Vector3d initial_state_x = {0.0, 0.0, 0.0}, initial_state_y = {0.0, -0.0, 0.0};
+    MatrixXd A;
+    VectorXd b;
+    FootScheduler replanning_schedule;
+    replanning_schedule.setSequence(LF, RH, RF, LH);
+    PlannerIni ini;
+    if (ini_path && std::strcmp(ini_path, "-")) ini = PlannerIni::read(ini_path);
+    const int optimizeVelocityFlag = ini.optimizeVelocity, useComStepCorrection = ini.useComStepCorrection;
+    Vector2d userSpeed = {ini.linearSpeedX, ini.linearSpeedY};
+    MPCPlanner myPlanner(horizon_size, Ts, 9.81);
+    LegDataMap<Vector2d> hips;
+    hips[LF] = {0.1, 1.0};
+    hips[RF] = {0.2, -1.0};
+    hips[LH] = {-0.4, 1.0};
+    hips[RH] = {-0.3, -1.0};
+    myPlanner.setHipOffsets(hips);
+    LegDataMap<MPCPlanner::footState> feetStates, footHolds;
+    LegDataMap<double> initial_feet_x, initial_feet_y;
+    initial_feet_x[LF] = initial_state_x[0] + 0.1;
+    initial_feet_x[RF] = initial_state_x[0] + 0.2;
+    initial_feet_x[LH] = initial_feet_x[LF] - 0.5;
+    initial_feet_x[RH] = initial_feet_x[RF] - 0.5;
+    initial_feet_y[LF] = initial_state_y[0] + 1.0;
+    initial_feet_y[RF] = initial_state_y[0] - 1.0;
+    initial_feet_y[LH] = initial_state_y[0] + 1.0;
+    initial_feet_y[RH] = initial_state_y[0] - 1.0;
+    Vector3d actual_state_x = initial_state_x, actual_state_y = initial_state_y;
+    const int replanningWindow = horizon_size / number_of_steps;
+    int sampleW = 0, replanningStage = 0;
+    VectorXd jerk_disturbance(experiment_duration, 0.0);
+    for (int k = 4; k < experiment_duration; k++) jerk_disturbance[k] = disturbance;
+    for (int sample = 0; sample < experiment_duration; sample++) {
+        if ((sample % replanningWindow) == 0) {
+            replanningStage++;
+            if (sample > 0) {
+                for (int leg = 0; leg < 4; leg++) {
+                    initial_feet_x[leg] = feetStates[leg].x[sampleW];
+                    initial_feet_y[leg] = feetStates[leg].y[sampleW];
+                }
+                replanning_schedule.next();
+            }
+            if (useComStepCorrection)
+                myPlanner.computeSteps(userSpeed, initial_feet_x, initial_feet_y, number_of_steps, horizon_size,
+                                       feetStates, footHolds, A, b, myPlanner, replanning_schedule.getCurrentSwing(),
+                                       Vector2d{actual_state_x[0], actual_state_y[0]});
+            else
+                myPlanner.computeSteps(userSpeed, initial_feet_x, initial_feet_y, number_of_steps, horizon_size,
+                                       feetStates, footHolds, A, b, myPlanner, replanning_schedule.getCurrentSwing());
+            if (!optimizeVelocityFlag) {
+                myPlanner.solveQPConstraintCoupled(height, actual_state_x, actual_state_y, A, b, jerk_x, jerk_y);
+            } else {
+                weight_R = 0.01;
+                myPlanner.setWeights(weight_R, weight_Q);
+                myPlanner.solveQPConstraintCoupled(height, actual_state_x, actual_state_y, A, b, userSpeed, jerk_x,
+                                                   jerk_y, replanningWindow);
+            }
+            sampleW = 0;
+            std::printf("stage%d_cost=%.12g\nstage%d_active=%d\nstage%d_status=%d\n", replanningStage,
+                        myPlanner.lastCost(), replanningStage, (int)myPlanner.lastActiveSet().size(), replanningStage,
+                        myPlanner.lastStatus());
+        } else {
+            sampleW++;
+        }
+        myPlanner.computeCOMupdate(actual_state_x, jerk_x[sampleW]);
+        myPlanner.computeCOMupdate(actual_state_y, jerk_y[sampleW] + jerk_disturbance[sample]);
+    }
+    std::printf("stages=%d\nx_pos=%.12g\nx_vel=%.12g\nx_acc=%.12g\ny_pos=%.12g\ny_vel=%.12g\ny_acc=%.12g\n",
+                replanningStage, actual_state_x[0], actual_state_x[1], actual_state_x[2], actual_state_y[0],
+                actual_state_y[1], actual_state_y[2]);
+    std::printf("speed_x=%.12g\nspeed_y=%.12g\n", userSpeed[0], userSpeed[1]);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     try {
         if (argc > 1 && !std::strcmp(argv[1], "coupled")) return coupled();
         if (argc > 1 && !std::strcmp(argv[1], "decoupled")) return decoupled(false);
         if (argc > 1 && !std::strcmp(argv[1], "decoupled_slack")) return decoupled(true);
         if (argc > 1 && !std::strcmp(argv[1], "qp")) return qp();
+        if (argc > 1 && !std::strcmp(argv[1], "replanning"))
+            return replanning(argc > 2 ? argv[2] : "-", argc > 3 ? std::atof(argv[3]) : 0.0,
+                              argc > 4 ? std::atoi(argv[4]) : 60);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 2;
     }
-    std::fprintf(stderr, "usage: %s coupled|decoupled|decoupled_slack|qp\n", argv[0]);
+    std::fprintf(stderr, "usage: %s coupled|decoupled|decoupled_slack|qp|replanning [ini|-] [disturbance] [duration]\n", argv[0]);
     return 1;
 }

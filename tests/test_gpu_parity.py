@@ -392,3 +392,34 @@ def test_cpp_dropin_drivers(P, tmp_path):
     assert ds["y_active"] >= 200 and ds["x_active"] >= 200  # every bound row carries its slack
     q = run("qp")
     assert abs(q["zmp99"] - 0.2) < 1e-2  # the ZMP follows the linear reference
+
+
+def test_cpp_replanning_driver_with_ini(P, oracle, tmp_path):
+    """The replanning driver rewritten against the C++ header (one planner call per replan, as
+    the reference does it), configured through a planner.ini, follows the same closed loop as
+    the CPU restatement of that driver."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "dropin_drivers")
+    ini = tmp_path / "planner.ini"
+    ini.write_text("[Graphics]\ndraw_cones = 0\n\n[Crawl]\n#a comment\ncycle_time = 4\nlinearSpeedX = 0.12\n"
+                   "linearSpeedY = 0.05 \nheadingSpeed = 0.0\n\n[Replanning]\nuseComStepCorrection = 1\n"
+                   "optimizeVelocity = 1\n")
+    r = subprocess.run([exe, "replanning", str(ini), "0.3", "60"], env=dict(os.environ, HOME=str(tmp_path)),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = {k: float(v) for k, v in (l.split("=") for l in r.stdout.splitlines() if "=" in l and " " not in l)}
+    assert (d["speed_x"], d["speed_y"], d["stages"]) == (0.12, 0.05, 6)
+    N, steps = 200, 20
+    ref = oracle.replanning_batch(oracle.params(N, R=0.01, Q=1.0, height=0.5, iter_cap=4000), steps, 6,
+                                  np.zeros((1, 3)), np.zeros((1, 3)), np.array([[0.12, 0.05]]),
+                                  np.array([[0.1, 0.2, -0.4, -0.3]]), np.array([[1.0, -1.0, 1.0, -1.0]]),
+                                  np.array([0], dtype=np.int32), np.array([0.3]), disturbance_start=4,
+                                  use_com_correction=True, hip=batches.NOMINAL_HIP_OFFSETS, nthreads=1)
+    for st in range(6):
+        assert d["stage%d_status" % (st + 1)] == ref["stage_status"][st, 0]
+        assert d["stage%d_active" % (st + 1)] == ref["stage_nactive"][st, 0]
+        assert d["stage%d_cost" % (st + 1)] == pytest.approx(ref["stage_cost"][st, 0], rel=RTOL)
+    got = np.array([d["x_pos"], d["x_vel"], d["x_acc"], d["y_pos"], d["y_vel"], d["y_acc"]])
+    want = np.r_[ref["x0"][0], ref["y0"][0]]
+    assert np.abs(got - want).max() < RTOL * np.abs(want).max()
