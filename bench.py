@@ -362,6 +362,18 @@ def main():
             r["traffic_unit"] = "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)"
             r["algorithmic_bytes_per_launch"] = wl.alg_bytes / wl.launches
             r["executed_f64_gflop_per_launch"] = (prof.get("executed_f64_flops_per_launch") or 0.0) / 1e9 or None
+            if r["executed_f64_gflop_per_launch"] and prof.get("avg_us"):
+                # hardware utilisation proper: fp64 operations the kernel really issued (FMA = 2)
+                # over its profiled duration, against the same vector peak
+                ex = r["executed_f64_gflop_per_launch"] / (prof["avg_us"] * 1e-6) / 1e3
+                r["executed_tflops"] = ex
+                r["executed_frac"] = ex / peak_tf
+            c = prof.get("counters_per_launch", {})
+            if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_WAVE_CYCLES"):
+                r["valu_busy_per_wave"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
+                r["wave_wait_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+                r["fp64_share_of_valu"] = ((c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0) +
+                                            c.get("SQ_INSTS_VALU_MUL_F64", 0)) / max(1.0, c.get("SQ_INSTS_VALU", 1.0)))
             r["profiled_kernel"] = prof.get("kernel")
             r["profiled_kernel_avg_ms"] = (prof.get("avg_us") or 0.0) / 1e3 or None
             r["profile_source"] = prof_file

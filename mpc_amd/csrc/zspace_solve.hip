@@ -303,6 +303,29 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
         }
         for (; a0 < n; a0 += 4) accum_group(M, a0, vx, vy, std::integral_constant<int, 4>{});
     };
+    // v += sum over phases of (reference of the phase) * Mp[phase, :], eight phases' loads in
+    // flight at a time (ZMP-reference formulation)
+    auto accum_phases = [&](const double *Mp, double *vx, double *vy) {
+        const int P = sd.nphase;
+        for (int p0 = 0; p0 < P; p0 += 8) {
+            double cxr[8], cyr[8], mv[8][NPL];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int p2 = p0 + j < P ? p0 + j : P - 1;
+                cxr[j] = p0 + j < P ? cref[2 * p2] : 0.0;
+                cyr[j] = p0 + j < P ? cref[2 * p2 + 1] : 0.0;
+#pragma unroll
+                for (int c = 0; c < NPL; c++) mv[j][c] = Mp[(size_t)p2 * N + kc[c]];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int c = 0; c < NPL; c++) {
+                    vx[c] += cxr[j] * mv[j][c];
+                    vy[c] += cyr[j] * mv[j][c];
+                }
+        }
+    };
     // coefficients of the working-set rows: coef * (p, q), zero-padded
     auto set_coefs = [&](double coef, int n) {
         if (lane < QL + 4) {
@@ -353,16 +376,7 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
         f = wave_sum(fp);
     }
     if constexpr (POLY) {
-        if (sd.Sp) // ZMP-reference formulation: response to the per-phase reference
-            for (int p2 = 0; p2 < sd.nphase; p2++) {
-                const double cxr = cref[2 * p2], cyr = cref[2 * p2 + 1];
-#pragma unroll
-                for (int c = 0; c < NPL; c++) {
-                    const double sv = sd.Sp[(size_t)p2 * N + kc[c]];
-                    zxu[c] += cxr * sv;
-                    zyu[c] += cyr * sv;
-                }
-            }
+        if (sd.Sp) accum_phases(sd.Sp, zxu, zyu); // ZMP-reference formulation: response to the per-phase reference
     }
 
     // ---- dual active-set loop ----------------------------------------------
@@ -762,16 +776,7 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
             vy[c] = k4[0] * wy[0] + k4[1] * wy[1] + k4[2] * wy[2] + k4[3] * wy[3];
         }
         if constexpr (POLY) {
-            if (Mp)
-                for (int p2 = 0; p2 < sd.nphase; p2++) {
-                    const double cxr = cref[2 * p2], cyr = cref[2 * p2 + 1];
-#pragma unroll
-                    for (int c = 0; c < NPL; c++) {
-                        const double mv = Mp[(size_t)p2 * N + kc[c]];
-                        vx[c] += cxr * mv;
-                        vy[c] += cyr * mv;
-                    }
-                }
+            if (Mp) accum_phases(Mp, vx, vy);
         }
         accum_rows(M, nresp, vx, vy);
 #pragma unroll
