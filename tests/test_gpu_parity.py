@@ -72,6 +72,38 @@ def test_coupled_other_shapes_vs_oracle(P, oracle, N, steps, rw):
     _check_coupled(o, ref, B)
 
 
+@pytest.mark.parametrize("N,steps", [(300, 15), (512, 16), (8, 2), (3, 1)])
+def test_coupled_extreme_horizons_vs_oracle(P, oracle, N, steps):
+    """Horizons beyond 256 knots (eight knots per lane, up to the maximum of 512) and tiny ones
+    (fewer knots than lanes; N=3 has empty swing phases)."""
+    B = 6 if N > 256 else 12
+    bt = batches.coupled_batch(B, first=3000)
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
+    o = _np(pl.solve_coupled(**bt))
+    ref = oracle.coupled_batch(oracle.params(N, R=0.01, Q=1.0, height=0.5, iter_cap=8000), oracle.COUPLED_VEL,
+                               steps, 1000, bt["x0"], bt["y0"], bt["speed"], bt["feet_x"], bt["feet_y"],
+                               bt["swing0"], nthreads=16)
+    _check_coupled(o, ref, B)
+
+
+def test_box_long_horizon_vs_oracle(P, oracle):
+    """Box problem with 300 knots: eight knots per lane in the first kernel, HBM-resident
+    factors in the dense one."""
+    B, N = 8, 300
+    bt = batches.decoupled_batch(B, N=N, steps=10, first=77)
+    pl = P.BatchedPlanner(N, formulation=P.BOX_1D, weight_R=1.0)
+    ref = oracle.box_batch(oracle.params(N, R=1.0, height=0.5, iter_cap=6000), bt["x0"], bt["y0"], bt["xmin"],
+                           bt["xmax"], bt["ymin"], bt["ymax"], nthreads=16)
+    o = _np(pl.solve_box(bt["y0"], bt["ymin"], bt["ymax"]))
+    assert (o["status"] == ref["status"][:, 1]).all()
+    ok = ref["status"][:, 1] == 0
+    assert ok.any()
+    for i in np.nonzero(ok)[0]:
+        na = ref["n_active"][i, 1]
+        assert list(o["active_idx"][i, :o["n_active"][i]]) == list(ref["active"][i, 1, :na])
+        assert _rel(o["jerk_x"][i], ref["jerk_y"][i]) < RTOL
+
+
 def test_coupled_com_step_correction(P, oracle):
     """computeSteps with an initial CoM (MPCPlanner.cpp:1231-1238, 1266-1283)."""
     B, N, steps = 16, 200, 20
