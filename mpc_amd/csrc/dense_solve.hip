@@ -18,6 +18,7 @@
 // The rotation angles of add_constraint (a sequential hypot chain in the reference)
 // are computed in parallel from suffix norms of d.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "device_common.h"
 #include "kernels.h"
@@ -95,8 +96,10 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
     int *redk = reinterpret_cast<int *>(red + 4);
     int *A = redk + 4, *A_old = A + (n + 1), *iai = A_old + (n + 1);
     int *iaexcl = iai + m;
-    // 8-byte aligned start of the LDS-resident matrices
-    double *lds_mats = reinterpret_cast<double *>((reinterpret_cast<size_t>(iaexcl + m) + 7) & ~(size_t)7);
+    // 8-byte aligned start of the LDS-resident matrices.  Plain pointer arithmetic on smem: a
+    // round trip through an integer would turn every access to J and R into a flat load.
+    const int ints_used = 4 + 2 * (n + 1) + 2 * m;
+    double *lds_mats = (red + 4) + (ints_used + 1) / 2;
     __shared__ int sh_i[4];
     // leading dimension of J: odd in LDS so that one thread per column walks conflict-free
     const int ldj = LDSJ ? (n | 1) : n;
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                 sh_i[0] = qq;
             }
             __syncthreads();
-            const int qq = sh_i[0];
+            const int qq = ufirst(sh_i[0]);
             {
                 const double c = (double)(iq - 1 - qq);
                 falg += 6.0 * nn * c + 3.0 * c * (c - 1.0);
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             }
             __syncthreads();
             for (int j = tid; j < iq; j += T) R[ridx(j, iq - 1)] = 0.0;
-            iq--;
+            iq = ufirst(iq - 1); // wave-uniform by construction; saying so keeps loop control scalar
             __syncthreads();
             if (iq == 0) return;
             // rotations of rows (j, j+1) of R: a true sequential chain
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                 DSTAMP(2);
                 if (bv < ss) {
                     ss = bv;
-                    ip = bi;
+                    ip = ufirst(bi);
                 }
                 if (ss >= 0.0) {
                     done = true;
@@ -490,6 +493,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                 }
                 __syncthreads();
                 for (;;) { // step 2a (l2a)
+                    iq = ufirst(iq);
                     passes++;
                     if (passes > sd.iter_cap) {
                         status = MPCB_ITER_CAP;
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                         __syncthreads();
                         for (int j = iq + 1 + tid; j < n; j += T) d[j] = 0.0;
                         for (int i = tid; i <= iq; i += T) R[ridx(i, iq)] = d[i];
-                        iq++;
+                        iq = ufirst(iq + 1);
                         __syncthreads();
                         const double dq = d[iq - 1];
                         if (fabs(dq) <= EPS * R_norm) { // degenerate (:400-418)
@@ -744,6 +748,8 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
 
         DSTAMP(9);
 #ifdef MPCB_STAMPS
+        stamp_acc[12] = passes;
+        stamp_acc[13] = iters;
         if (tid == 0 && sd.dbg)
             for (int i = 0; i < 16; i++) sd.dbg[(size_t)inst * 16 + i] = stamp_acc[i];
 #endif
@@ -846,7 +852,8 @@ hipError_t launch_dense(const DevSetup &sd, const DevIn &in, const mpcb_outputs 
     if (blocks <= 0) return hipSuccess;
     const bool poly = sd.form != MPCB_BOX_1D;
     // 160 KB of LDS per workgroup at most; keep a margin for the static part
-    const bool ldsj = dense_lds_bytes(sd, true) <= 160 * 1024 - 256;
+    bool ldsj = dense_lds_bytes(sd, true) <= 160 * 1024 - 256;
+    if (getenv("MPCB_EXPERIMENT_NO_LDSJ")) ldsj = false;
     const size_t shmem = dense_lds_bytes(sd, ldsj);
     const void *fn;
     if (sd.form == MPCB_BOX_SLACK)

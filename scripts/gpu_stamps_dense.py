@@ -16,7 +16,9 @@ out = pl.solve_box_prepared(prep); torch.cuda.synchronize()
 st = out["status"].cpu().numpy(); d = dbg.cpu().numpy().astype(np.float64)
 bad = st == 1
 print("infeasible", bad.sum(), "iters mean", out["iters"].cpu().numpy()[bad].mean())
-tot = d[bad].sum(axis=1)
+tot = d[bad][:, :12].sum(axis=1)
 print("mean cycles per infeasible instance (dense kernel, wave-kernel stamps overwritten): %.0f" % tot.mean())
 for i, n in enumerate(names):
     print("  %-14s %10.0f  %5.1f%%" % (n, d[bad][:, i].mean(), 100 * d[bad][:, i].sum() / tot.sum()))
+print("passes mean %.0f max %.0f, outer iterations mean %.0f; cycles per pass %.0f; max cycles %.3g" % (
+    d[bad][:, 12].mean(), d[bad][:, 12].max(), d[bad][:, 13].mean(), tot.sum() / d[bad][:, 12].sum(), tot.max()))
