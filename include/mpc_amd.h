@@ -72,7 +72,12 @@ typedef struct {
     double  weight_Qs;          /* ZMP-reference weight (COUPLED_REF), slack weight (BOX_SLACK) */
     int32_t replanning_window;  /* 1000 = constant velocity weights (MPCPlanner.cpp:535);
                                    otherwise Gaussian weights, makeGaussian (:1161-1171) */
-    int32_t number_of_steps;    /* computeSteps' number_of_steps (coupled only)    */
+    int32_t number_of_steps;    /* computeSteps' number_of_steps (coupled only).  0 = no
+                                   footstep schedule: every knot k owns rows 4k .. 4k+3
+                                   (m = 4N); with rows_pqr the caller fills them, e.g. from
+                                   a time-based gait, a row that does not exist being
+                                   (0, 0, +INFINITY); without rows_pqr all knots get the
+                                   polygon of the initial feet                       */
     double  hip_offsets[8];     /* [leg][x,y]; the reference reads them uninitialised
                                    unless setHipOffsets was called; here explicit  */
     int32_t iter_cap;           /* cap on outer iterations and on step-direction passes;

@@ -85,6 +85,120 @@ class FootScheduler {
     int cur_ = 0;
 };
 
+// One-shot timer on an externally supplied clock (timer.h:11-75).
+class Timer {
+  public:
+    void startTimer(double startTime) {
+        T0_ = startTime;
+        resetFlag = false;
+    }
+    void setDuration(double dur) { duration_ = dur; }
+    double getDuration() const { return duration_; }
+    double getMissingTime(double time) const {
+        if (resetFlag) return duration_;
+        return (time - T0_) <= duration_ ? duration_ - (time - T0_) : 0.0;
+    }
+    double getElapsedTime(double time) const { return time - T0_; }
+    bool isTimeElapsed(double time) const { return resetFlag || (time - T0_) > duration_; }
+    bool changeDuration(double time, double newDuration) {
+        if (newDuration > getElapsedTime(time)) {
+            duration_ = newDuration;
+            return true;
+        }
+        return false;
+    }
+    void resetTimer() { resetFlag = true; }
+    bool resetFlag = true;
+
+  private:
+    double T0_ = 0.0, duration_ = 0.0;
+};
+
+// Time-based gait schedule (GaitSequencer.h:18-222): a stride phase in [0, 1) advances by
+// dt / cycleDuration per update; the leg in sequence slot i lifts off when the phase passes
+// offset[i] and stays in swing for (1 - dutyFactor[i]) of a cycle.
+class GaitSequencer {
+  public:
+    GaitSequencer() { speed_ = 1.0 / cycleDuration_; }
+    GaitSequencer(LegID leg1, LegID leg2, LegID leg3, LegID leg4, int taskServoRate) {
+        setSequence(leg1, leg2, leg3, leg4);
+        dt_ = 1.0 / (double)taskServoRate;
+        dutyFactor_ = {0.75, 0.75, 0.75, 0.75};
+        speed_ = 1.0 / cycleDuration_;
+    }
+    void setTaskServoRate(int taskServoRate) { dt_ = 1.0 / (double)taskServoRate; }
+    void setSequence(LegID leg1, LegID leg2, LegID leg3, LegID leg4) { seq_ = {leg1, leg2, leg3, leg4}; }
+    void setOffsetAboutCycleStart(double o0, double o1, double o2, double o3) { offset_ = {o0, o1, o2, o3}; }
+    void setTotalCycleDuration(double totalCycleTime) {
+        cycleDuration_ = totalCycleTime;
+        speed_ = std::fabs(cycleDuration_) < 0.001 ? 0.0 : 1.0 / cycleDuration_;
+        for (int i = 0; i < 4; i++) timer_[i].setDuration(1.0 - dutyFactor_[i]);
+        computeSwingDuration(cycleDuration_);
+    }
+    void setDutyFactor(double d0, double d1, double d2, double d3) {
+        dutyFactor_ = {d0, d1, d2, d3};
+        for (int i = 0; i < 4; i++) {
+            timer_[i].setDuration(1.0 - dutyFactor_[i]);
+            timer_[i].resetTimer();
+        }
+        computeSwingDuration(cycleDuration_);
+    }
+    void computeSwingDuration(double totalCycleTime) {
+        for (int i = 0; i < 4; i++) swingDuration_[i] = totalCycleTime * (1.0 - dutyFactor_[i]);
+    }
+    // once per control step; prepareSwinging[leg] is raised on the lift-off edge of that leg
+    void updateGaitScheduler(LegDataMap<bool> &prepareSwinging, bool &detected_switch) {
+        stride_ += speed_ * dt_;
+        strideNotReset_ += speed_ * dt_;
+        updateSwingStatus(strideNotReset_, stride_);
+        if (stride_ >= (1.0 + speed_ * dt_)) { // the extra dt keeps the last leg of the cycle
+            stride_ = 0.0;
+            waitForCycleReset_ = {false, false, false, false};
+        }
+        for (int i = 0; i < 4; i++) {
+            const bool rising = (swing_[i] != swingOld_[i]) && swing_[i];
+            if (rising) {
+                prepareSwinging[seq_[i]] = true;
+                detected_switch = true;
+            }
+        }
+        swingOld_ = swing_;
+    }
+    LegDataMap<bool> getSwingLegState() const {
+        LegDataMap<bool> status = {false, false, false, false};
+        for (int i = 0; i < 4; i++) status[seq_[i]] = swing_[i];
+        return status;
+    }
+    double getSwingDuration(LegID leg) const {
+        for (int i = 0; i < 4; i++)
+            if (seq_[i] == leg) return swingDuration_[i];
+        return swingDuration_[0];
+    }
+    double getStrideParametrization() const { return stride_; }
+
+  private:
+    void updateSwingStatus(double s_notReset, double s) {
+        for (int i = 0; i < 4; i++) {
+            if (timer_[i].resetFlag) {
+                if (s > offset_[i] && !waitForCycleReset_[i]) {
+                    timer_[i].startTimer(s_notReset);
+                    swing_[i] = true;
+                }
+            } else if (timer_[i].isTimeElapsed(s_notReset)) {
+                swing_[i] = false;
+                waitForCycleReset_[i] = true;
+                timer_[i].resetTimer();
+            }
+        }
+    }
+    double speed_ = 0.25, stride_ = 0.0, strideNotReset_ = 0.0, cycleDuration_ = 4.0, dt_ = 1.0 / 250.0;
+    std::array<double, 4> dutyFactor_ = {0.75, 0.75, 0.75, 0.75}, offset_ = {0, 0, 0, 0}, swingDuration_ = {0, 0, 0, 0};
+    std::array<LegID, 4> seq_ = {LF, RF, LH, RH};
+    std::array<Timer, 4> timer_;
+    std::array<bool, 4> swing_ = {false, false, false, false}, swingOld_ = {false, false, false, false},
+                        waitForCycleReset_ = {false, false, false, false};
+};
+
 // The planner-related keys of the reference's config/planner.ini: [Crawl] linearSpeedX,
 // linearSpeedY (the per-step displacement / velocity target handed to computeSteps and the
 // velocity formulation) and [Replanning] useComStepCorrection, optimizeVelocity (the two
@@ -520,9 +634,13 @@ class MPCPlanner {
                        const VectorXd *zrefx, const VectorXd *zrefy, const MatrixXd &A, const VectorXd &b,
                        const Vector2d &speed, VectorXd &jerk_x, VectorXd &jerk_y, int rw) {
         const int N = horizon_size_;
-        need(number_of_steps_ > 0, "call computeSteps before a coupled solve (it fixes the row structure)");
         need(A.cols() == 2 * N && A.rows() == (int)b.size(), "A must be m x 2N and b of size m");
         last_height_ = height;
+        if (number_of_steps_ <= 0 || A.rows() != rows_of_schedule(N, number_of_steps_)) {
+            // rows that do not come from computeSteps (e.g. polygons of a time-based gait)
+            solve_coupled_free(formulation, height, x0, y0, zrefx, zrefy, A, b, speed, jerk_x, jerk_y, rw);
+            return;
+        }
         mpcb_handle h = handle(formulation, height, rw, number_of_steps_);
         const int m = mpcb_num_constraints(h), nph = mpcb_num_phases(h);
         need(A.rows() == m, "A does not have the rows computeSteps produces for this horizon/steps");
@@ -561,6 +679,66 @@ class MPCPlanner {
         mpcb_outputs o = outputs(jerk_x.data(), jerk_y.data());
         check(mpcb_solve_coupled(h, 1, &in, &o));
         finish(o);
+    }
+    static int rows_of_schedule(int N, int steps) { // rows computeSteps leaves in A (:1324-1326)
+        const int pd = (N / steps) / 2;
+        return 7 * pd * steps + 4 * (N - 2 * pd * steps);
+    }
+    // Any A, b whose rows each constrain the ZMP at ONE knot (p at column k, q at column
+    // k + N), at most four rows per knot.  Knot k's rows go to slots 4k .. 4k+3 of a
+    // schedule-free handle in the order they appear in A; for the solver to break ties the way
+    // the reference does (lowest row of A first) the rows of A should be ordered by knot, as
+    // buildPolygonMatrix leaves them when the phases are appended in time order.
+    void solve_coupled_free(int formulation, double height, const Vector3d &x0, const Vector3d &y0,
+                            const VectorXd *zrefx, const VectorXd *zrefy, const MatrixXd &A, const VectorXd &b,
+                            const Vector2d &speed, VectorXd &jerk_x, VectorXd &jerk_y, int rw) {
+        const int N = horizon_size_, m = A.rows();
+        mpcb_handle h = handle(formulation, height, rw, 0);
+        std::vector<double> rows((size_t)N * 12);
+        for (int i = 0; i < 4 * N; i++) {
+            rows[3 * i] = 0.0;
+            rows[3 * i + 1] = 0.0;
+            rows[3 * i + 2] = HUGE_VAL;
+        }
+        std::vector<int> used(N, 0), slot_row((size_t)4 * N, -1);
+        for (int r = 0; r < m; r++) {
+            int k = -1;
+            for (int j = 0; j < N; j++)
+                if (A(r, j) != 0.0 || A(r, j + N) != 0.0) {
+                    need(k < 0, "a row of A touches more than one knot");
+                    k = j;
+                }
+            need(k >= 0, "a row of A is empty");
+            need(used[k] < 4, "more than four rows on one knot");
+            const int s = 4 * k + used[k]++;
+            rows[3 * s] = A(r, k);
+            rows[3 * s + 1] = A(r, k + N);
+            rows[3 * s + 2] = b[r];
+            slot_row[s] = r;
+        }
+        std::vector<double> zph(2, 0.0);
+        if (zrefx) {
+            for (int k = 0; k < N; k++)
+                need((*zrefx)[k] == (*zrefx)[0] && (*zrefy)[k] == (*zrefy)[0],
+                     "without a footstep schedule the ZMP reference must be constant over the horizon");
+            zph[0] = (*zrefx)[0];
+            zph[1] = (*zrefy)[0];
+        }
+        jerk_x.assign(N, 0.0);
+        jerk_y.assign(N, 0.0);
+        mpcb_coupled_inputs in = {};
+        in.x0 = x0.data();
+        in.y0 = y0.data();
+        in.speed = speed.data();
+        in.rows_pqr = rows.data();
+        in.zref_phase = zrefx ? zph.data() : nullptr;
+        mpcb_outputs o = outputs(jerk_x.data(), jerk_y.data());
+        last_active_.assign(4 * N, -1);
+        o.active_idx = last_active_.data();
+        o.active_stride = (int)last_active_.size();
+        check(mpcb_solve_coupled(h, 1, &in, &o));
+        finish(o);
+        for (int &a : last_active_) a = slot_row[a]; // back to rows of A
     }
     // which: 0 position, 1 velocity, 2 acceleration, 3 ZMP (uses the height of the last solve)
     void rollout(const Vector3d &x0, const VectorXd &jerk, VectorXd &out, int which) const {

@@ -333,6 +333,7 @@ int mpcb_replan_sweep_device(mpcb_handle h, int32_t B, int32_t n_stages, int32_t
         return fail(MPCB_E_ARG, "missing replanning state array");
     if (!out->jerk_x || !out->jerk_y || !out->cost || !out->status)
         return fail(MPCB_E_ARG, "replanning needs the jerk_x, jerk_y, cost and status outputs");
+    if (h->hs.steps < 1) return fail(MPCB_E_ARG, "replanning needs number_of_steps >= 1");
     const int window = h->hs.N / h->hs.steps; // replanningWindow (testPlannerXYconstraintMPC.cpp:95)
     if (window < 1) return fail(MPCB_E_ARG, "horizon shorter than number_of_steps");
     DeviceGuard guard(h->params.device);

@@ -245,6 +245,16 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             if constexpr (SLACK) f += 0.5 * (2.0 * N) * sd.slack_g0 * slack_x0; // 1/2 g0'x (:191)
         }
         for (int i = tid; i < m; i += T) iai[i] = i;
+        // stopping threshold (eiquadprog.hpp:267) on the rows the caller really has: empty slots
+        // of caller-built rows ((0, 0, +inf)) do not count
+        double psi_thr = sd.psi_thr;
+        if constexpr (POLY) {
+            if (rows) {
+                double mine = 0.0;
+                for (int i = tid; i < m; i += T) mine += rows[i * 3 + 2] < DINF ? 1.0 : 0.0;
+                psi_thr = sd.psi_thr * (block_sum(mine, red, tid) / (double)m);
+            }
+        }
         double R_norm = 1.0;
         int iq = 0, iters = 0, passes = 0, status = MPCB_OK;
         int ip = 0;
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             double part = 0.0;
             for (int i = tid; i < m; i += T) part += fmin(0.0, s[i]);
             const double psi = block_sum(part, red, tid);
-            if (fabs(psi) <= sd.psi_thr) break;
+            if (fabs(psi) <= psi_thr) break;
             for (int i = tid; i < iq; i += T) {
                 u_old[i] = u[i];
                 A_old[i] = A[i];

@@ -299,20 +299,22 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
     o.knot_row0.assign(N, 0);
     if (coupled) {
         const int steps = p.number_of_steps;
-        if (steps < 1 || steps > 255) {
-            *err = "number_of_steps must be in [1, 255]";
+        if (steps < 0 || steps > 255) {
+            *err = "number_of_steps must be in [0, 255]";
             return MPCB_E_ARG;
         }
         // computeSteps (MPCPlanner.cpp:1200,1209): step_knots = floor(N/steps),
         // phase_duration = floor(step_knots/2); per step a 4-stance then a 3-stance
         // phase; the knots left over form a final 4-stance phase (:1309-1321).
-        const int step_knots = N / steps, pd = step_knots / 2;
+        // steps == 0: no footstep schedule -- every knot belongs to the trailing phase and
+        // owns four rows (4k .. 4k+3), which the caller fills (rows_pqr).
+        const int step_knots = steps > 0 ? N / steps : 0, pd = step_knots / 2;
         const int covered = 2 * pd * steps;
         o.steps = steps;
         o.phase_knots = pd;
         o.nphase = 2 * steps + 1;
         o.m = 7 * pd * steps + 4 * (N - covered);
-        if (o.m > 4 * step_knots * steps) {
+        if (steps > 0 && o.m > 4 * step_knots * steps) {
             *err = "horizon/number_of_steps leaves more trailing knots than computeSteps has rows for";
             return MPCB_E_ARG;
         }

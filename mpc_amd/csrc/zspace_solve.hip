@@ -379,6 +379,21 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
         if (sd.Sp) accum_phases(sd.Sp, zxu, zyu); // ZMP-reference formulation: response to the per-phase reference
     }
 
+    // Stopping threshold m * eps * c1 * c2 * 100 (eiquadprog.hpp:267): m is the number of rows
+    // of the problem.  Caller-built rows may leave slots empty ((0, 0, +inf)); those are not
+    // rows of the caller's A and do not count.
+    double psi_thr = sd.psi_thr;
+    if constexpr (ROWS) {
+        int mine = 0;
+#pragma unroll
+        for (int c = 0; c < NPL; c++)
+#pragma unroll
+            for (int e = 0; e < ES; e++)
+                if ((validm & (1u << (4 * c + e))) && slotR(c, e) < DINF) mine++;
+        const int m_eff = (int)wave_sum((double)mine);
+        psi_thr = ufirst(sd.psi_thr * ((double)m_eff / (double)sd.m));
+    }
+
     // ---- dual active-set loop ----------------------------------------------
     int iq = 0, iters = 0, passes = 0, status = MPCB_OK;
     // operation count of the dense method along this pivot sequence (diagnostic)
@@ -459,7 +474,7 @@ __global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup 
         psi = wave_sum(psi);
         falg += 2 * mm * nn;
         exclm = 0xffffffffu; // iaexcl[i] = true (:257)
-        if (fabs(psi) <= sd.psi_thr) { // :267-272
+        if (fabs(psi) <= psi_thr) { // :267-272
             zmp_current = true;
             break;
         }

@@ -248,12 +248,118 @@ static int replanning(const char *ini_path, double disturbance, int experiment_d
     return 0;
 }
 
+// tests/generateGait/generateFootSteps.cpp (time-based gaits: 0 crawl, 1 pace, 2 trot, 3 bound)
+// with its prompts' defaults, followed by what that driver leaves commented out: the
+// support polygons of the generated stance pattern (buildPolygonMatrix per run of identical
+// knots) and a coupled velocity-formulation solve over them.  The rows of A, b are written to
+// $HOME/gait_rows.txt as "row knot p q r" for cross-checks.
+static int gait(int gaitType, double duty_factor) {
+    int horizon_size = 200;
+    double Ts = 0.04, cycle_time = 4.0;
+    Vector2d userSpeed = {0.05, 0.0};
+    MPCPlanner myPlanner(horizon_size, Ts, 9.81);
+    GaitSequencer myGaitSchedule;
+    myGaitSchedule.setTaskServoRate((int)(1 / Ts));
+    double offset_gait[4] = {0.0, 0.25, 0.5, 0.75};
+    switch (gaitType) {
+    case 0: myGaitSchedule.setSequence(RH, RF, LH, LF); break;
+    case 1:
+        myGaitSchedule.setSequence(RH, RF, LH, LF);
+        offset_gait[1] = 0.0, offset_gait[2] = 0.5, offset_gait[3] = 0.5;
+        break;
+    case 2:
+        myGaitSchedule.setSequence(RH, LF, LH, RF);
+        offset_gait[1] = 0.0, offset_gait[2] = 0.5, offset_gait[3] = 0.5;
+        break;
+    default:
+        myGaitSchedule.setSequence(RH, LH, RF, LF);
+        offset_gait[1] = 0.0, offset_gait[2] = 0.5, offset_gait[3] = 0.5;
+        break;
+    }
+    myGaitSchedule.setDutyFactor(duty_factor, duty_factor, duty_factor, duty_factor);
+    myGaitSchedule.setOffsetAboutCycleStart(offset_gait[0], offset_gait[1], offset_gait[2], offset_gait[3]);
+    myGaitSchedule.setTotalCycleDuration(cycle_time);
+    LegDataMap<MPCPlanner::footState> feetStates;
+    LegDataMap<double> feetValuesX = {0.3, 0.3, -0.3, -0.3}, feetValuesY = {0.3, -0.3, 0.3, -0.3};
+    for (int leg = 0; leg < 4; leg++) feetStates[leg].resize(horizon_size);
+    LegDataMap<bool> swingingFlag = {false, false, false, false};
+    bool detected_switch = false;
+    for (int i = 0; i < horizon_size; i++) {
+        myGaitSchedule.updateGaitScheduler(swingingFlag, detected_switch);
+        const LegDataMap<bool> swing = myGaitSchedule.getSwingLegState();
+        for (int leg = 0; leg < 4; leg++) {
+            feetStates[leg].x[i] = feetValuesX[leg];
+            feetStates[leg].y[i] = feetValuesY[leg];
+            feetStates[leg].swing[i] = swing[leg];
+        }
+        if (detected_switch) {
+            for (int leg = 0; leg < 4; leg++)
+                if (swing[leg]) {
+                    feetValuesX[leg] += cycle_time * duty_factor * userSpeed[0];
+                    feetValuesY[leg] += cycle_time * duty_factor * userSpeed[1];
+                }
+            detected_switch = false;
+        }
+    }
+    myPlanner.saveTraj("swingLF.txt", feetStates[LF].swing, false);
+    myPlanner.saveTraj("footPosLF.txt", feetStates[LF].x, feetStates[LF].y, false);
+    // polygons: one buildPolygonMatrix call per run of knots with the same stance pattern and feet
+    MatrixXd A;
+    VectorXd b;
+    A.resize(4 * horizon_size, 2 * horizon_size);
+    b.assign((size_t)4 * horizon_size, 0.0);
+    int nc = 0, start = 0, min_stance = 4;
+    auto same = [&](int a, int c) {
+        for (int leg = 0; leg < 4; leg++)
+            if (feetStates[leg].swing[a] != feetStates[leg].swing[c] || feetStates[leg].x[a] != feetStates[leg].x[c] ||
+                feetStates[leg].y[a] != feetStates[leg].y[c])
+                return false;
+        return true;
+    };
+    for (int k = 1; k <= horizon_size; k++)
+        if (k == horizon_size || !same(start, k)) {
+            int stance = 0;
+            for (int leg = 0; leg < 4; leg++) stance += feetStates[leg].swing[start] ? 0 : 1;
+            min_stance = std::min(min_stance, stance);
+            if (stance >= 2) myPlanner.buildPolygonMatrix(feetStates, start, k - start, horizon_size, A, b, nc);
+            start = k;
+        }
+    MatrixXd A2;
+    A2.resize(nc, 2 * horizon_size);
+    for (int j = 0; j < 2 * horizon_size; j++)
+        for (int i = 0; i < nc; i++) A2(i, j) = A(i, j);
+    b.resize(nc);
+    {
+        const std::string path = std::string(std::getenv("HOME") ? std::getenv("HOME") : ".") + "/gait_rows.txt";
+        std::FILE *f = std::fopen(path.c_str(), "w");
+        for (int r = 0; r < nc; r++)
+            for (int k = 0; k < horizon_size; k++)
+                if (A2(r, k) != 0.0 || A2(r, k + horizon_size) != 0.0)
+                    std::fprintf(f, "%d %d %.17g %.17g %.17g\n", r, k, A2(r, k), A2(r, k + horizon_size), b[r]);
+        std::fclose(f);
+    }
+    VectorXd jerk_x, jerk_y, com_x;
+    Vector3d x0 = {0.0, 0.0, 0.0}, y0 = {0.0, 0.0, 0.0};
+    myPlanner.setWeights(0.01, 1.0);
+    myPlanner.solveQPConstraintCoupled(0.5, x0, y0, A2, b, userSpeed, jerk_x, jerk_y);
+    myPlanner.computeCOMtrajectory(x0, jerk_x, com_x);
+    std::printf("rows=%d\nmin_stance=%d\nstatus=%d\nn_active=%d\ncost=%.12g\njerk_x0=%.12g\njerk_y0=%.12g\ncom_x_last=%.12g\n", nc,
+                min_stance, myPlanner.lastStatus(), (int)myPlanner.lastActiveSet().size(), myPlanner.lastCost(),
+                jerk_x[0], jerk_y[0], com_x[horizon_size - 1]);
+    std::printf("active_rows=");
+    for (int a : myPlanner.lastActiveSet()) std::printf("%d,", a);
+    std::printf("\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
     try {
         if (argc > 1 && !std::strcmp(argv[1], "coupled")) return coupled();
         if (argc > 1 && !std::strcmp(argv[1], "decoupled")) return decoupled(false);
         if (argc > 1 && !std::strcmp(argv[1], "decoupled_slack")) return decoupled(true);
         if (argc > 1 && !std::strcmp(argv[1], "qp")) return qp();
+        if (argc > 1 && !std::strcmp(argv[1], "gait"))
+            return gait(argc > 2 ? std::atoi(argv[2]) : 0, argc > 3 ? std::atof(argv[3]) : 0.85);
         if (argc > 1 && !std::strcmp(argv[1], "replanning"))
             return replanning(argc > 2 ? argv[2] : "-", argc > 3 ? std::atof(argv[3]) : 0.0,
                               argc > 4 ? std::atoi(argv[4]) : 60);
@@ -261,6 +367,6 @@ int main(int argc, char **argv) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 2;
     }
-    std::fprintf(stderr, "usage: %s coupled|decoupled|decoupled_slack|qp|replanning [ini|-] [disturbance] [duration]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s coupled|decoupled|decoupled_slack|qp|replanning [ini|-] [disturbance] [duration]|gait [type] [duty]\n", argv[0]);
     return 1;
 }

@@ -230,7 +230,15 @@ def test_empty_batch_and_bad_arguments(P):
     with pytest.raises(P.MpcError):
         P.BatchedPlanner(0, formulation=P.BOX_1D)
     with pytest.raises(P.MpcError):
-        P.BatchedPlanner(200, formulation=P.COUPLED_VEL, number_of_steps=0)
+        P.BatchedPlanner(200, formulation=P.COUPLED_VEL, number_of_steps=-1)
+    with pytest.raises(P.MpcError):
+        P.BatchedPlanner(200, formulation=P.COUPLED_VEL, number_of_steps=256)
+    # number_of_steps = 0: no footstep schedule, every knot gets the polygon of the initial feet
+    bt = batches.coupled_batch(4)
+    stand = P.BatchedPlanner(40, formulation=P.COUPLED_JERK, weight_R=0.01, number_of_steps=0)
+    assert stand.num_constraints == 160
+    o = _np(stand.solve_coupled(**bt))
+    assert (o["status"] == 0).all() and (o["min_margin"] > -4e-3).all()
 
 
 @pytest.mark.parametrize("Qs,rw", [(100.0, 1000), (0.1, 1000), (1.0, 10)])
@@ -455,3 +463,36 @@ def test_cpp_replanning_driver_with_ini(P, oracle, tmp_path):
     got = np.array([d["x_pos"], d["x_vel"], d["x_acc"], d["y_pos"], d["y_vel"], d["y_acc"]])
     want = np.r_[ref["x0"][0], ref["y0"][0]]
     assert np.abs(got - want).max() < RTOL * np.abs(want).max()
+
+
+@pytest.mark.parametrize("gait,duty", [(0, 0.85), (0, 0.7), (2, 0.6)])
+def test_cpp_gait_driver(P, oracle, tmp_path, gait, duty):
+    """Support polygons of a time-based gait (GaitSequencer: crawl with 3- and 4-foot phases,
+    crawl with a duty factor that leaves two-foot phases, trot) solved through the
+    schedule-free row layout; the CPU restatement solves the same A, b."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "dropin_drivers")
+    r = subprocess.run([exe, "gait", str(gait), str(duty)], env=dict(os.environ, HOME=str(tmp_path)),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = dict(l.split("=") for l in r.stdout.splitlines() if "=" in l and " " not in l)
+    N = 200
+    rows = np.loadtxt(tmp_path / "gait_rows.txt").reshape(-1, 5)
+    m = int(d["rows"])
+    assert len(rows) == m and (np.diff(rows[:, 1]) >= 0).all()  # one knot per row, knot-major
+    A = np.zeros((m, 2 * N))
+    b = np.zeros(m)
+    for rr, k, p, q, c in rows:
+        A[int(rr), int(k)], A[int(rr), int(k) + N], b[int(rr)] = p, q, c
+    swing = np.loadtxt(tmp_path / "swingLF.txt")[:, 1]
+    assert 0 < swing.sum() < N  # the left-front leg both swings and stands
+    ref = oracle.solve_coupled(oracle.params(N, Ts=0.04, R=0.01, Q=1.0, height=0.5, iter_cap=8000),
+                               oracle.COUPLED_VEL, np.zeros(3), np.zeros(3), A, b, np.array([0.05, 0.0]), 1000)
+    assert int(d["status"]) == ref["info"].status
+    if ref["info"].status == 0:
+        got_active = [int(a) for a in d["active_rows"].split(",") if a]
+        assert got_active == list(ref["active"])
+        assert float(d["cost"]) == pytest.approx(ref["info"].f, rel=RTOL)
+        assert float(d["jerk_x0"]) == pytest.approx(ref["jerk_x"][0], rel=RTOL, abs=1e-9)
+        assert float(d["jerk_y0"]) == pytest.approx(ref["jerk_y"][0], rel=RTOL, abs=1e-9)
