@@ -559,30 +559,37 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
 #pragma unroll
                                 for (int q8 = 0; q8 < 8; q8++) {
                                     const int k = k0 - q8;
-                                    c0v[q8] = (k >= 0 && lane < k) ? R[ridx(lane, k)] : 0.0;
-                                    c1v[q8] = (k >= 0 && lane + 64 < k) ? R[ridx(lane + 64, k)] : 0.0;
+                                    // always a valid address (row clamped into the column), masked
+                                    // afterwards: no branch around the load
+                                    const int kk = k >= 0 ? k : 0;
+                                    const double a0 = R[ridx(lane < kk ? lane : kk, kk)];
+                                    const double a1 = R[ridx(lane + 64 < kk ? lane + 64 : kk, kk)];
+                                    // the reciprocal pivot goes into the column here, off the chain
+                                    const double ivsel = kk >= 64 ? iv1 : iv0;
+                                    const double inv = __hiloint2double(
+                                        __builtin_amdgcn_readlane(__double2hiint(ivsel), kk & 63),
+                                        __builtin_amdgcn_readlane(__double2loint(ivsel), kk & 63));
+                                    c0v[q8] = (k >= 0 && lane < k) ? a0 * inv : 0.0;
+                                    c1v[q8] = (k >= 0 && lane + 64 < k) ? a1 * inv : 0.0;
                                 }
+                                // chain: acc_i -= (R_ik / R_kk) * acc_k -- one broadcast and one FMA
+                                // per column; acc_k is final once the columns above k are done, and
+                                // r_k = acc_k / R_kk is formed for all k at the end
 #pragma unroll
                                 for (int q8 = 0; q8 < 8; q8++) {
                                     const int k = k0 - q8;
                                     if (k >= 0) {
-                                        const double ivsel = k >= 64 ? iv1 : iv0;
-                                        const double inv = __hiloint2double(
-                                            __builtin_amdgcn_readlane(__double2hiint(ivsel), k & 63),
-                                            __builtin_amdgcn_readlane(__double2loint(ivsel), k & 63));
-                                        const double rsel = k >= 64 ? r1 : r0;
-                                        const int lo32 = __builtin_amdgcn_readlane(__double2loint(rsel), k & 63);
-                                        const int hi32 = __builtin_amdgcn_readlane(__double2hiint(rsel), k & 63);
-                                        const double rk = __hiloint2double(hi32, lo32) * inv;
-                                        r0 -= c0v[q8] * rk;
-                                        r1 -= c1v[q8] * rk;
-                                        if (lane == (k & 63)) {
-                                            if (k >= 64) r1 = rk;
-                                            else r0 = rk;
-                                        }
+                                        const double asel = k >= 64 ? r1 : r0;
+                                        const double ak = __hiloint2double(
+                                            __builtin_amdgcn_readlane(__double2hiint(asel), k & 63),
+                                            __builtin_amdgcn_readlane(__double2loint(asel), k & 63));
+                                        r0 = fma(-c0v[q8], ak, r0);
+                                        r1 = fma(-c1v[q8], ak, r1);
                                     }
                                 }
                             }
+                            r0 *= iv0;
+                            r1 *= iv1;
                             if (lane < iq) r[lane] = r0;
                             if (lane + 64 < iq) r[lane + 64] = r1;
                         }
