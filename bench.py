@@ -243,7 +243,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # under torch.distributed.run (RANK and MASTER_ADDR set) the process group is used even with
+    # one rank, so that a one-GPU box exercises the same code as an eight-GPU node
+    distributed = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
