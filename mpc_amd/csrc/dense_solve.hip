@@ -869,8 +869,7 @@ hipError_t launch_dense(const DevSetup &sd, const DevIn &in, const mpcb_outputs 
     if (blocks <= 0) return hipSuccess;
     const bool poly = sd.form != MPCB_BOX_1D;
     // 160 KB of LDS per workgroup at most; keep a margin for the static part
-    bool ldsj = dense_lds_bytes(sd, true) <= 160 * 1024 - 256;
-    if (getenv("MPCB_EXPERIMENT_NO_LDSJ")) ldsj = false;
+    const bool ldsj = dense_lds_bytes(sd, true) <= 160 * 1024 - 256;
     const size_t shmem = dense_lds_bytes(sd, ldsj);
     const void *fn;
     if (sd.form == MPCB_BOX_SLACK)

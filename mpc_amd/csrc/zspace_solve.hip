@@ -15,7 +15,7 @@
 // (R'R = N_A' G^-1 N_A, which is also the R of the reference's QR update) and its
 // inverse.  Both live in LDS; nothing n x n or m x n is ever formed.
 //
-// Layout: 256-thread blocks = 4 independent waves, no workgroup barrier anywhere.
+// Layout: one 64-thread workgroup (a single wave) per QP, no workgroup barrier anywhere.
 // Lane l owns knots l, l+64, ... and the (at most 4) constraint rows of each of
 // them, in registers.  Cross-lane data goes through the wave's private LDS slice
 // or through wave shuffles.
@@ -167,13 +167,13 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
 // ROWS: polygon rows come from the caller (in.rows_pqr, the (p, q, r) of every row of the
 // A, b that computeSteps returned, possibly edited) instead of being built from the feet.
 template <int NPL, bool POLY, bool ROWS>
-__global__ __launch_bounds__(256, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
+__global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
                                                       int *unresolved_list, int *unresolved_count) {
     constexpr int ES = POLY ? 4 : 2;
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63;
     const int wv = ufirst((int)(threadIdx.x >> 6));
-    const int inst = ufirst((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int inst = ufirst((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (inst >= B) return;
     const int N = sd.N;
 #ifdef MPCB_STAMPS
@@ -844,16 +844,19 @@ template <int NPL, bool POLY, bool ROWS>
 hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
                       const DenseWs &ws, hipStream_t stream) {
     const size_t per_wave = sizeof(WaveState) + (POLY ? ((size_t)sd.nphase * 14 + 12) * 8 : 0);
-    size_t shmem = 4 * per_wave;
-    if (const char *pad = getenv("MPCB_EXPERIMENT_LDS_PAD")) shmem += (size_t)atoi(pad);
+    // One wave (= one QP) per workgroup: waves never wait for each other, so a workgroup's LDS
+    // and wave slot are released the moment its QP is done instead of when the slowest of
+    // several is (iteration counts differ by 2-3x between instances).
+    const int wpb = 1;
+    size_t shmem = (size_t)wpb * per_wave;
     auto kfn = zspace_kernel<NPL, POLY, ROWS>;
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    const int blocks = (B + 3) / 4;
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), shmem, stream, sd, in, out, B, ws.list, ws.count);
+    const int blocks = (B + wpb - 1) / wpb;
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64 * wpb), shmem, stream, sd, in, out, B, ws.list, ws.count);
     return hipGetLastError();
 }
 
