@@ -561,7 +561,9 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
             }
             ucand = 0.0; // u(iq) = 0 (:297)
             pending = true;
-            const double mii = ufirst((pip * pip + qip * qip) * sd.S[(size_t)kip * N + kip]);
+            // n_ip' G^-1 n_ip; the load is consumed after the gather of the first pass has been
+            // issued, so that the two memory round trips overlap
+            const double skk = sd.S[(size_t)kip * N + kip];
 
             for (;;) { // step 2a (l2a), :306-446
                 passes++;
@@ -580,6 +582,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 }
                 W.g[lane < QL ? lane : QL] = ga;
                 wsync();
+                const double mii = ufirst((pip * pip + qip * qip) * skk);
                 STAMP(4);
                 {
                     // d_i = sum_j Rinv[j][i] g_j, r_i = sum_k Rinv[i][k] d_k: plain sums, the

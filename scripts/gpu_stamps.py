@@ -6,9 +6,10 @@ import numpy as np, torch
 from mpc_amd import batches, planner as P
 names = ["prologue", "l1 rows", "s eval+psi", "select", "g gather", "d,r", "zn+t1", "add writes (+drop)", "zmp/margin out", "t2,t", "f,u,rho", "-", "scalars/active out", "jerk out", "com,vel out", "-"]
 def run(wl, B):
-    if wl == "coupled":
+    if wl in ("coupled", "jerk"):
         bt = batches.coupled_batch(B)
-        pl = P.BatchedPlanner(200, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=20)
+        pl = P.BatchedPlanner(200, formulation=P.COUPLED_VEL if wl == "coupled" else P.COUPLED_JERK,
+                              weight_R=0.01, weight_Q=1.0, number_of_steps=20)
         prep = pl.prepare_coupled(**bt); call = lambda: pl.solve_coupled_prepared(prep)
     else:
         bt = batches.decoupled_batch(B)
@@ -28,4 +29,5 @@ def run(wl, B):
     for i, n in enumerate(names[:15]):
         print("  %-14s %9.0f cycles  %5.1f%%" % (n, d[:, i].mean(), 100 * d[:, i].sum() / tot.sum()))
 run("coupled", 8192)
+run("jerk", 8192)
 run("box", 4096)
