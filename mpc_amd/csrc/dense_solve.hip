@@ -47,7 +47,10 @@ __device__ __forceinline__ double block_sum(double v, double *red, int tid) {
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    double tot = red[0];
+#pragma unroll
+    for (int w = 1; w < T / 64; w++) tot += red[w];
+    return tot;
 }
 
 // minimum of (val, key), smaller key wins ties; result identical in every thread
@@ -63,7 +66,7 @@ __device__ __forceinline__ void block_argmin(double &val, int &key, double *red,
     val = red[0];
     key = redk[0];
 #pragma unroll
-    for (int w = 1; w < 4; w++)
+    for (int w = 1; w < T / 64; w++)
         if (red[w] < val || (red[w] == val && redk[w] < key)) {
             val = red[w];
             key = redk[w];
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                             d[j] = acc;
                         }
                     } else {
-                        for (int j = wave; j < n; j += 4) {
+                        for (int j = wave; j < n; j += T / 64) {
                             const double *col = J + (size_t)j * ldj;
                             double acc = 0.0;
                             for (int k = lane; k < n; k += 64) acc += col[k] * np[k];
