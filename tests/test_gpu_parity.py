@@ -172,6 +172,31 @@ def test_box_slack_variant_vs_oracle(P, oracle, N, R, Qs):
     assert np.allclose(o["min_margin"], np.minimum(o["zmp_x"] - bb["ymin"], bb["ymax"] - o["zmp_x"]))
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("cap", [3, 7])
+def test_iteration_cap_vs_oracle(P, oracle, cap, mode):
+    """The cap on outer iterations / step-direction passes (this build's addition; the reference
+    loops without one): same status, same working set and the same partially constrained plan as
+    the CPU restatement with the same cap, in both kernels."""
+    B, N, steps = 32, 200, 20
+    bt = batches.coupled_batch(B, first=640)
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=steps,
+                          iter_cap=cap, solver_mode=mode)
+    o = _np(pl.solve_coupled(**bt))
+    ref = oracle.coupled_batch(oracle.params(N, R=0.01, Q=1.0, height=0.5, iter_cap=cap), oracle.COUPLED_VEL,
+                               steps, 1000, bt["x0"], bt["y0"], bt["speed"], bt["feet_x"], bt["feet_y"],
+                               bt["swing0"], nthreads=16)
+    assert (ref["status"] == 2).any()  # the cap binds for part of the batch
+    assert (o["status"] == ref["status"]).all()
+    assert (o["n_active"] == ref["n_active"]).all()
+    for i in range(B):
+        na = ref["n_active"][i]
+        assert list(o["active_idx"][i, :na]) == list(ref["active"][i, :na])
+        for k in ("jerk_x", "jerk_y", "com_x", "zmp_y"):
+            assert _rel(o[k][i], ref[k][i]) < RTOL, (k, i)
+    assert (np.abs(o["cost"] - ref["cost"]) <= RTOL * np.abs(ref["cost"])).all()
+
+
 def test_default_driver_scenarios(P):
     """The recorded outputs of the reference's two default drivers, through the GPU path."""
     import json, os
