@@ -214,6 +214,30 @@ class DecoupledWorkload:
         return {"workload": self.name, "xy_pairs_per_gpu": self.B, "horizon": self.N,
                 "variables": 100, "constraints": 200, "weights": {"R": 1.0}, "seed": batches.SEED}
 
+    def feasible_subset(self, steps=10):
+        """Throughput over the pairs whose two QPs are feasible (the infeasible X-axis draws, kept in
+        the batch on purpose, each cost hundreds of passes of the second-stage kernel)."""
+        ok = ((self.outx[0]["status"] == 0) & (self.outy[0]["status"] == 0)).cpu().numpy()
+        i = {k: v[ok] for k, v in self.inputs.items()}
+        n = int(ok.sum())
+        if n == 0:
+            return None
+        px = self.pl.prepare_box(i["x0"], i["xmin"], i["xmax"])
+        py = self.pl.prepare_box(i["y0"], i["ymin"], i["ymax"])
+        ox = self.pl._alloc_outputs(n, P.ALL_OUTPUTS)
+        oy = self.pl._alloc_outputs(n, P.ALL_OUTPUTS)
+        for _ in range(2):
+            self.pl.solve_box_prepared(px, out=ox)
+            self.pl.solve_box_prepared(py, out=oy)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            self.pl.solve_box_prepared(px, out=ox)
+            self.pl.solve_box_prepared(py, out=oy)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / steps
+        return {"pairs": n, "value": n / dt, "unit": "solves/s", "ms_per_step": dt * 1e3}
+
     def cpu_baseline(self, threads, sample):
         from oracle import oracle as O
         p = O.params(self.N, R=1.0, height=0.5, dense=1, iter_cap=3000)
@@ -353,10 +377,14 @@ def main():
                 "working_set_mean": float(n_active.mean()),
                 "working_set_max": int(n_active.max()),
                 "outer_iterations_mean": float(iters.mean()),
+                # instances of the last call that needed the dense second-stage kernel
+                "second_stage_instances": wl.pl.last_handover_count(),
             },
         }
         if epilogue is not None:
             line["epilogue_best_cost"] = epilogue
+        if hasattr(wl, "feasible_subset"):
+            line["feasible_subset"] = wl.feasible_subset()
         prof, prof_file = measured_profile(args.workload)
         if prof is not None:
             r = line["roofline"]

@@ -198,6 +198,11 @@ int  mpcb_solve_unconstrained_device(mpcb_handle h, int32_t B, const double *x0,
 int  mpcb_solve_unconstrained(mpcb_handle h, int32_t B, const double *x0, const double *zmp_ref,
                               const mpcb_outputs *out);
 
+/* Diagnostic, no counterpart in the reference: how many instances of the handle's most recent
+ * solve the first-stage kernel handed over to the dense second-stage kernel (working set
+ * beyond its capacity, or a numerically singular reduced system).  Waits for the device. */
+int  mpcb_last_handover_count(mpcb_handle h);
+
 /* Copy an instance-independent matrix to the host (tests, diagnostics).
  * which: 0 = S (ZMP response, N x N), 1 = W^T (jerk response), 2 = CoM position
  * response, 3 = CoM velocity response, 4 = Kz (N x 4), 5 = Kx (N x 4).      */

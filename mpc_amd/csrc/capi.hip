@@ -274,6 +274,16 @@ int mpcb_debug_set_stamp_buffer(mpcb_handle h, long long *dev) {
     return 0;
 }
 
+int mpcb_last_handover_count(mpcb_handle h) {
+    if (!h) return fail(MPCB_E_ARG, "null handle");
+    if (!h->ws.count) return 0;
+    DeviceGuard guard(h->params.device);
+    int n = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&n, h->ws.count, sizeof(int), hipMemcpyDeviceToHost));
+    return n;
+}
+
 int mpcb_get_matrix(mpcb_handle h, int32_t which, double *dst) {
     if (!h || !dst) return fail(MPCB_E_ARG, "null argument");
     const mpcb::HostSetup &hs = h->hs;

@@ -575,6 +575,9 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                                     c0v[q8] = (k >= 0 && lane < k) ? a0 * inv : 0.0;
                                     c1v[q8] = (k >= 0 && lane + 64 < k) ? a1 * inv : 0.0;
                                 }
+                                // keep the loads of the group ahead of the chain (the scheduler would
+                                // otherwise sink each load next to its use and serialise on LDS latency)
+                                __builtin_amdgcn_sched_barrier(0);
                                 // chain: acc_i -= (R_ik / R_kk) * acc_k -- one broadcast and one FMA
                                 // per column; acc_k is final once the columns above k are done, and
                                 // r_k = acc_k / R_kk is formed for all k at the end

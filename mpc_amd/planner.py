@@ -23,7 +23,7 @@ MODE_AUTO, MODE_DENSE = 0, 1
 EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constraints", "mpcb_num_phases",
            "mpcb_solve_coupled_device", "mpcb_solve_coupled", "mpcb_solve_box_device",
            "mpcb_solve_box", "mpcb_get_matrix", "mpcb_replan_sweep_device",
-           "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained")
+           "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained", "mpcb_last_handover_count")
 
 
 class Params(C.Structure):
@@ -77,6 +77,7 @@ def load_library():
         lib.mpcb_solve_box_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_get_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.mpcb_last_handover_count.argtypes = [C.c_void_p]
         lib.mpcb_solve_unconstrained_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                                         C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_replan_sweep_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -185,6 +186,10 @@ class BatchedPlanner:
         if stream is None:
             stream = self._torch.cuda.current_stream(self.device)
         return C.c_void_p(stream.cuda_stream)
+
+    def last_handover_count(self):
+        """Instances of the most recent solve that went through the dense second-stage kernel."""
+        return _check(load_library().mpcb_last_handover_count(self._h))
 
     def matrix(self, which):
         """Instance-independent tables (0 S, 1 W^T, 2 CoM, 3 CoM velocity: N x N;
