@@ -88,7 +88,11 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
     // ---- LDS carve-up -------------------------------------------------------
     double *x = smem, *z = x + n, *d = z + n, *np = d + n, *x_old = np + n;
     double *u = x_old + n, *u_old = u + (n + 1), *r = u_old + (n + 1);
-    double *rc = r + (n + 1), *rs = rc + n, *rx = rs + n, *suf = rx + n; // rotation cos/sin/xny, suffix norms
+    // rotation cos / sin / sin/(1+cos) per column, suffix norms; rb = -cos, or +1 where a column
+    // pair is left unrotated: (new, carried) = (c t1 + s t2, s t1 + rb t2) then needs no test
+    // rb shares the storage of z: the step direction is dead from the moment x has been
+    // updated until the next pass recomputes it, which is exactly when rotations happen
+    double *rc = r + (n + 1), *rs = rc + n, *rx = rs + n, *rb = z, *suf = rx + n;
     double *s = suf + (n + 1);
     double *zx = s + m, *zy = zx + N;
     double *lo = zy + N, *hi = lo + N;                                   // BOX limits
@@ -322,6 +326,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                                 rc[j] = 1.0;
                                 rs[j] = 0.0;
                                 rx[j] = DINF;
+                                rb[j] = 1.0;
                             }
                             if (k0 >= j && k0 < iq) R[ridx(j, k0)] = top0;
                             if (k1 >= j && k1 < iq) R[ridx(j, k1)] = top1;
@@ -340,6 +345,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                             rc[j] = cc;
                             rs[j] = ss;
                             rx[j] = xny;
+                            rb[j] = -cc;
                         }
                         if (k0 == j || k1 == j) {
                             R[ridx(j, j)] = hd;
@@ -367,6 +373,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                         rc[j] = 1.0;
                         rs[j] = 0.0;
                         rx[j] = DINF; // marks "no rotation"
+                        rb[j] = 1.0;
                     } else {
                         cc /= h;
                         ss /= h;
@@ -380,6 +387,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                         rc[j] = cc;
                         rs[j] = ss;
                         rx[j] = ss / (1.0 + cc);
+                        rb[j] = -cc;
                     }
                 }
                 __syncthreads();
@@ -406,23 +414,15 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     for (int q8 = 0; q8 < 8; q8++) {
                         const bool in = j0 + q8 < iq;
                         t2v[q8] = in ? J[(size_t)(j0 + q8 + 1) * ldj + row] : 0.0;
-                        cv[q8] = in ? rc[j0 + q8] : 1.0;
-                        sv[q8] = in ? rs[j0 + q8] : 0.0;
-                        xv[q8] = in ? rx[j0 + q8] : DINF;
+                        cv[q8] = in ? rc[j0 + q8] : 0.0;
+                        sv[q8] = in ? rs[j0 + q8] : 1.0;
+                        xv[q8] = in ? rb[j0 + q8] : 0.0;
                     }
+                    // past the last column (c, s, b, t2) = (0, 1, 0, 0) leaves the carried value alone
 #pragma unroll
                     for (int q8 = 0; q8 < 8; q8++) {
-                        const int j = j0 + q8;
-                        if (j < iq) {
-                            if (xv[q8] == DINF) {
-                                outv[q8] = t1;
-                                t1 = t2v[q8];
-                            } else {
-                                const double nv = t1 * cv[q8] + t2v[q8] * sv[q8];
-                                outv[q8] = nv;
-                                t1 = xv[q8] * (nv + t1) - t2v[q8];
-                            }
-                        }
+                        outv[q8] = fma(t1, cv[q8], t2v[q8] * sv[q8]);
+                        t1 = fma(t1, sv[q8], t2v[q8] * xv[q8]);
                     }
 #pragma unroll
                     for (int q8 = 0; q8 < 8; q8++)
@@ -677,6 +677,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                                 rx[j] = DINF;
                                 rc[j] = 1.0;
                                 rs[j] = 0.0;
+                                rb[j] = 1.0;
                             } else {
                                 double cur = (j == n - 1) ? d[j] : (d[j] < 0.0 ? -suf[j] : suf[j]);
                                 double cc = d[j - 1] / h, sv = cur / h;
@@ -687,6 +688,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                                 rc[j] = cc;
                                 rs[j] = sv;
                                 rx[j] = sv / (1.0 + cc);
+                                rb[j] = -cc;
                             }
                         }
                         __syncthreads();
@@ -700,23 +702,16 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                                     for (int q8 = 0; q8 < 8; q8++) {
                                         const bool in = j0 - q8 >= iq + 1;
                                         t1v[q8] = in ? J[(size_t)(j0 - q8 - 1) * ldj + row] : 0.0;
-                                        cv[q8] = in ? rc[j0 - q8] : 1.0;
-                                        sv[q8] = in ? rs[j0 - q8] : 0.0;
-                                        xv[q8] = in ? rx[j0 - q8] : DINF;
+                                        // past the first column (c, s, b, t1) = (0, 1, 0, 0) leaves
+                                        // the carried value alone
+                                        cv[q8] = in ? rc[j0 - q8] : 0.0;
+                                        sv[q8] = in ? rs[j0 - q8] : 1.0;
+                                        xv[q8] = in ? rb[j0 - q8] : 0.0;
                                     }
 #pragma unroll
                                     for (int q8 = 0; q8 < 8; q8++) {
-                                        const int j = j0 - q8;
-                                        if (j >= iq + 1) {
-                                            if (xv[q8] == DINF) {
-                                                outv[q8] = t2c;
-                                                t2c = t1v[q8];
-                                            } else {
-                                                const double nv = t1v[q8] * cv[q8] + t2c * sv[q8];
-                                                outv[q8] = xv[q8] * (t1v[q8] + nv) - t2c;
-                                                t2c = nv;
-                                            }
-                                        }
+                                        outv[q8] = fma(t2c, xv[q8], t1v[q8] * sv[q8]);
+                                        t2c = fma(t2c, sv[q8], t1v[q8] * cv[q8]);
                                     }
 #pragma unroll
                                     for (int q8 = 0; q8 < 8; q8++)
@@ -725,7 +720,9 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                                 J[(size_t)iq * ldj + row] = t2c;
                             }
                         }
+                        DSTAMP(14);
                         __syncthreads();
+                        DSTAMP(15);
                         if (tid == 0) {
                             if (n - 1 >= iq + 1 && suf[iq] != 0.0) d[iq] = d[iq] < 0.0 ? -suf[iq] : suf[iq];
                         }
