@@ -22,6 +22,7 @@
 
 #include "device_common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace mpcb {
 namespace {
@@ -408,17 +409,22 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             // two loads would otherwise serialise them).
             for (int row = tid; row < n; row += T) {
                 double t1 = J[(size_t)qq * ldj + row];
-                for (int j0 = qq; j0 < iq; j0 += 8) {
+                // FULL: all eight columns exist, nothing is tested.  Otherwise the loads go to a
+                // clamped (always valid) column and the values are replaced by the padding
+                // (c, s, b, t2) = (0, 1, 0, 0), which leaves the carried value alone.
+                auto group = [&](int j0, auto full) {
+                    constexpr bool FULL = decltype(full)::value;
                     double t2v[8], outv[8], cv[8], sv[8], xv[8];
 #pragma unroll
                     for (int q8 = 0; q8 < 8; q8++) {
-                        const bool in = j0 + q8 < iq;
-                        t2v[q8] = in ? J[(size_t)(j0 + q8 + 1) * ldj + row] : 0.0;
-                        cv[q8] = in ? rc[j0 + q8] : 0.0;
-                        sv[q8] = in ? rs[j0 + q8] : 1.0;
-                        xv[q8] = in ? rb[j0 + q8] : 0.0;
+                        const bool in = FULL || j0 + q8 < iq;
+                        const int jc = FULL ? j0 + q8 : min(j0 + q8, iq - 1);
+                        const double a = J[(size_t)(jc + 1) * ldj + row], b = rc[jc], c = rs[jc], e = rb[jc];
+                        t2v[q8] = in ? a : 0.0;
+                        cv[q8] = in ? b : 0.0;
+                        sv[q8] = in ? c : 1.0;
+                        xv[q8] = in ? e : 0.0;
                     }
-                    // past the last column (c, s, b, t2) = (0, 1, 0, 0) leaves the carried value alone
 #pragma unroll
                     for (int q8 = 0; q8 < 8; q8++) {
                         outv[q8] = fma(t1, cv[q8], t2v[q8] * sv[q8]);
@@ -426,8 +432,11 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     }
 #pragma unroll
                     for (int q8 = 0; q8 < 8; q8++)
-                        if (j0 + q8 < iq) J[(size_t)(j0 + q8) * ldj + row] = outv[q8];
-                }
+                        if (FULL || j0 + q8 < iq) J[(size_t)(j0 + q8) * ldj + row] = outv[q8];
+                };
+                int j0 = qq;
+                for (; j0 + 8 <= iq; j0 += 8) group(j0, std::true_type{});
+                if (j0 < iq) group(j0, std::false_type{});
                 J[(size_t)iq * ldj + row] = t1;
             }
             __syncthreads();
@@ -696,17 +705,21 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                         for (int row = tid; row < n; row += T) {
                             if (n - 1 >= iq + 1) {
                                 double t2c = J[(size_t)(n - 1) * ldj + row];
-                                for (int j0 = n - 1; j0 >= iq + 1; j0 -= 8) {
+                                // as in delete_constraint: untested full groups, then one group
+                                // with clamped loads and the padding (c, s, b, t1) = (0, 1, 0, 0)
+                                auto group = [&](int j0, auto full) {
+                                    constexpr bool FULL = decltype(full)::value;
                                     double t1v[8], outv[8], cv[8], sv[8], xv[8];
 #pragma unroll
                                     for (int q8 = 0; q8 < 8; q8++) {
-                                        const bool in = j0 - q8 >= iq + 1;
-                                        t1v[q8] = in ? J[(size_t)(j0 - q8 - 1) * ldj + row] : 0.0;
-                                        // past the first column (c, s, b, t1) = (0, 1, 0, 0) leaves
-                                        // the carried value alone
-                                        cv[q8] = in ? rc[j0 - q8] : 0.0;
-                                        sv[q8] = in ? rs[j0 - q8] : 1.0;
-                                        xv[q8] = in ? rb[j0 - q8] : 0.0;
+                                        const bool in = FULL || j0 - q8 >= iq + 1;
+                                        const int jc = FULL ? j0 - q8 : max(j0 - q8, iq + 1);
+                                        const double a = J[(size_t)(jc - 1) * ldj + row], b = rc[jc], c = rs[jc],
+                                                     e = rb[jc];
+                                        t1v[q8] = in ? a : 0.0;
+                                        cv[q8] = in ? b : 0.0;
+                                        sv[q8] = in ? c : 1.0;
+                                        xv[q8] = in ? e : 0.0;
                                     }
 #pragma unroll
                                     for (int q8 = 0; q8 < 8; q8++) {
@@ -715,8 +728,11 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                                     }
 #pragma unroll
                                     for (int q8 = 0; q8 < 8; q8++)
-                                        if (j0 - q8 >= iq + 1) J[(size_t)(j0 - q8) * ldj + row] = outv[q8];
-                                }
+                                        if (FULL || j0 - q8 >= iq + 1) J[(size_t)(j0 - q8) * ldj + row] = outv[q8];
+                                };
+                                int j0 = n - 1;
+                                for (; j0 - 7 >= iq + 1; j0 -= 8) group(j0, std::true_type{});
+                                if (j0 >= iq + 1) group(j0, std::false_type{});
                                 J[(size_t)iq * ldj + row] = t2c;
                             }
                         }
