@@ -43,35 +43,60 @@ constexpr int T = 256;
     } while (0)
 #endif
 
-__device__ __forceinline__ double block_sum(double v, double *red, int tid) {
+// The reductions exchange per-wave partials through one of two small LDS buffers, taken in
+// turn (flip): a wave can still be reading the buffer of the previous reduction while another
+// already writes this one's, and the barrier of this reduction orders it against the one after
+// next -- so each reduction needs a single barrier.
+constexpr int NW = T / 64, RED_D = 3 * NW, RED_I = NW;
+
+__device__ __forceinline__ double block_sum(double v, double *red, int tid, int &flip) {
     v = wave_sum(v);
+    double *b = red + flip * RED_D;
+    flip ^= 1;
+    if ((tid & 63) == 0) b[tid >> 6] = v;
     __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    double tot = red[0];
+    double tot = b[0];
 #pragma unroll
-    for (int w = 1; w < T / 64; w++) tot += red[w];
+    for (int w = 1; w < NW; w++) tot += b[w];
     return tot;
 }
 
 // minimum of (val, key), smaller key wins ties; result identical in every thread
-__device__ __forceinline__ void block_argmin(double &val, int &key, double *red, int *redk, int tid) {
+// and, in the same exchange, the sums of a and b
+__device__ __forceinline__ void block_argmin_sums(double &val, int &key, double &a, double &b, double *red,
+                                                  int *redk, int tid, int &flip) {
     int aux = 0;
     wave_argmin(val, key, aux);
-    __syncthreads();
+    a = wave_sum(a);
+    b = wave_sum(b);
+    double *bd = red + flip * RED_D;
+    int *bk = redk + flip * RED_I;
+    flip ^= 1;
     if ((tid & 63) == 0) {
-        red[tid >> 6] = val;
-        redk[tid >> 6] = key;
+        bd[tid >> 6] = val;
+        bk[tid >> 6] = key;
+        bd[NW + (tid >> 6)] = a;
+        bd[2 * NW + (tid >> 6)] = b;
     }
     __syncthreads();
-    val = red[0];
-    key = redk[0];
+    val = bd[0];
+    key = bk[0];
+    a = bd[NW];
+    b = bd[2 * NW];
 #pragma unroll
-    for (int w = 1; w < T / 64; w++)
-        if (red[w] < val || (red[w] == val && redk[w] < key)) {
-            val = red[w];
-            key = redk[w];
+    for (int w = 1; w < NW; w++) {
+        if (bd[w] < val || (bd[w] == val && bk[w] < key)) {
+            val = bd[w];
+            key = bk[w];
         }
+        a += bd[NW + w];
+        b += bd[2 * NW + w];
+    }
+}
+
+__device__ __forceinline__ void block_argmin(double &val, int &key, double *red, int *redk, int tid, int &flip) {
+    double a = 0.0, b = 0.0;
+    block_argmin_sums(val, key, a, b, red, redk, tid, flip);
 }
 
 // LDSJ: J (n x n) and R (packed, one sub-diagonal) live in the workgroup's LDS instead of
@@ -101,13 +126,14 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
     double *tab = zc + N;                                                // POLY: [phase][edge][p,q,r]
     double *cref = tab + (POLY ? sd.nphase * 12 : 0);                    // POLY: [phase][x,y]
     double *red = cref + (POLY ? sd.nphase * 2 : 0);
-    int *redk = reinterpret_cast<int *>(red + 4);
-    int *A = redk + 4, *A_old = A + (n + 1), *iai = A_old + (n + 1);
+    int *redk = reinterpret_cast<int *>(red + 2 * RED_D);
+    int *A = redk + 2 * RED_I, *A_old = A + (n + 1), *iai = A_old + (n + 1);
+    int flip = 0;
     int *iaexcl = iai + m;
     // 8-byte aligned start of the LDS-resident matrices.  Plain pointer arithmetic on smem: a
     // round trip through an integer would turn every access to J and R into a flat load.
-    const int ints_used = 4 + 2 * (n + 1) + 2 * m;
-    double *lds_mats = (red + 4) + (ints_used + 1) / 2;
+    const int ints_used = 2 * RED_I + 2 * (n + 1) + 2 * m;
+    double *lds_mats = (red + 2 * RED_D) + (ints_used + 1) / 2;
     __shared__ int sh_i[4];
     // leading dimension of J: odd in LDS so that one thread per column walks conflict-free
     const int ldj = LDSJ ? (n | 1) : n;
@@ -181,36 +207,69 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             if constexpr (POLY) return rows ? rows[i * 3 + 2] : tab[(sd.knot_phase[k] * 4 + ws.row_slot[i]) * 3 + 2];
             else return i < N ? -lo[k] : hi[k];
         };
-        // s_i = n_i' x + ci0_i through the ZMP: zx = Zx x0 + Zu x  (never forms CI)
-        auto eval_s = [&](int only) {
-            for (int k = tid; k < N; k += T) {
-                const double *zr = ws.zx + (size_t)k * 3;
-                double ax = zr[0] * wx[0] + zr[1] * wx[1] + zr[2] * wx[2];
-                double ay = zr[0] * wy[0] + zr[1] * wy[1] + zr[2] * wy[2];
+        // s_i = n_i' x + ci0_i through the ZMP: zx = Zx x0 + Zu x  (never forms CI).
+        // value of row i given the ZMP (zxk, zyk) of its knot
+        auto row_value = [&](int i, int k, double zxk, double zyk) -> double {
+            if constexpr (SLACK) {
+                if (i >= 2 * N) return -x[N + (i - 2 * N)];
+                return (i < N ? zxk - lo[k] : hi[k] - zxk) + x[N + i];
+            } else {
+                return rowP(i, k) * zxk + rowQ(i, k) * zyk + rowR(i, k);
+            }
+        };
+        auto row_knot = [&](int i) -> int {
+            if constexpr (SLACK) return i >= 2 * N ? 0 : (i < N ? i : i - N);
+            else return rowK(i);
+        };
+        // all rows: the triangular product Zu x is cut into NW column bands, one per wave, lanes
+        // over the knots; the bands' partial sums (kept in the rotation coefficient arrays, which
+        // are dead between updates of the factor) are added in a fixed order per row.  Ends with
+        // s written but NOT yet visible to other threads: the caller's next barrier does that.
+        auto eval_all = [&]() {
+            double *part = wave == 0 ? rc : wave == 1 ? rs : wave == 2 ? rx : suf;
+            const int band = (N + NW - 1) / NW, j0 = wave * band;
+            for (int k = lane; k < N; k += 64) {
+                double ax = 0.0, ay = 0.0;
+                if (wave == 0) {
+                    const double *zr = ws.zx + (size_t)k * 3;
+                    ax = zr[0] * wx[0] + zr[1] * wx[1] + zr[2] * wx[2];
+                    ay = zr[0] * wy[0] + zr[1] * wy[1] + zr[2] * wy[2];
+                }
+                const int j1 = min(k, j0 + band - 1);
 #pragma unroll 8
-                for (int j = 0; j <= k; j++) {
+                for (int j = j0; j <= j1; j++) {
                     const double c = zc[k - j];
                     ax += c * x[j];
                     if constexpr (POLY) ay += c * x[N + j];
                 }
-                zx[k] = ax;
-                zy[k] = ay;
+                part[k] = ax;
+                if constexpr (POLY) part[N + k] = ay;
             }
             __syncthreads();
-            auto row_value = [&](int i) -> double {
-                if constexpr (SLACK) {
-                    if (i >= 2 * N) return -x[N + (i - 2 * N)];
-                    const int k = i < N ? i : i - N;
-                    return (i < N ? zx[k] - lo[k] : hi[k] - zx[k]) + x[N + i];
-                } else {
-                    const int k = rowK(i);
-                    return rowP(i, k) * zx[k] + rowQ(i, k) * zy[k] + rowR(i, k);
+            for (int i = tid; i < m; i += T) {
+                const int k = row_knot(i);
+                const double zxk = ((rc[k] + rs[k]) + rx[k]) + suf[k];
+                double zyk = 0.0;
+                if constexpr (POLY) zyk = ((rc[N + k] + rs[N + k]) + rx[N + k]) + suf[N + k];
+                s[i] = row_value(i, k, zxk, zyk);
+            }
+        };
+        // one row: a single dot product, lanes of wave 0 over the jerks
+        auto eval_one = [&](int i) {
+            if (wave == 0) {
+                const int k = row_knot(i);
+                double ax = 0.0, ay = 0.0;
+                for (int j = lane; j <= k; j += 64) {
+                    const double c = zc[k - j];
+                    ax += c * x[j];
+                    if constexpr (POLY) ay += c * x[N + j];
                 }
-            };
-            if (only >= 0) {
-                if (tid == 0) s[only] = row_value(only);
-            } else {
-                for (int i = tid; i < m; i += T) s[i] = row_value(i);
+                ax = wave_sum(ax);
+                if constexpr (POLY) ay = wave_sum(ay);
+                const double *zr = ws.zx + (size_t)k * 3;
+                ax += zr[0] * wx[0] + zr[1] * wx[1] + zr[2] * wx[2];
+                ay += zr[0] * wy[0] + zr[1] * wy[1] + zr[2] * wy[2];
+                if (lane == 0) s[i] = row_value(i, k, ax, ay);
             }
             __syncthreads();
         };
@@ -249,7 +308,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             for (int pb = 0; pb < (sd.F2 ? sd.nphase : 1); pb += T)
                 fp += unconstrained_cost_part(sd, wx, cref, 0, pb + tid, pb + tid == 0) +
                       unconstrained_cost_part(sd, wy, cref, 1, pb + tid, pb + tid == 0);
-            f = block_sum(fp, red, tid);
+            f = block_sum(fp, red, tid, flip);
             if constexpr (SLACK) f += 0.5 * (2.0 * N) * sd.slack_g0 * slack_x0; // 1/2 g0'x (:191)
         }
         for (int i = tid; i < m; i += T) iai[i] = i;
@@ -260,7 +319,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             if (rows) {
                 double mine = 0.0;
                 for (int i = tid; i < m; i += T) mine += rows[i * 3 + 2] < DINF ? 1.0 : 0.0;
-                psi_thr = sd.psi_thr * (block_sum(mine, red, tid) / (double)m);
+                psi_thr = sd.psi_thr * (block_sum(mine, red, tid, flip) / (double)m);
             }
         }
         double R_norm = 1.0;
@@ -272,31 +331,41 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
 
         // delete_constraint (eiquadprog.hpp:516-592); u has iq+1 live entries
         auto delete_constraint = [&](int l) {
-            if (tid == 0) {
-                int qq = 0;
-                for (int i = 0; i < iq; i++)
-                    if (A[i] == l) {
-                        qq = i;
-                        break;
-                    }
-                sh_i[0] = qq;
-            }
+            // position of l in the working set (its entries are distinct: one thread finds it)
+            for (int i = tid; i < iq; i += T)
+                if (A[i] == l) sh_i[0] = i;
             __syncthreads();
             const int qq = ufirst(sh_i[0]);
             {
                 const double c = (double)(iq - 1 - qq);
                 falg += 6.0 * nn * c + 3.0 * c * (c - 1.0);
             }
-            // shift A, u and the columns of R
+            // shift the columns of R: one thread per row, eight entries read before any is written
             for (int row = tid; row < iq; row += T)
-                for (int i = (qq > row - 1 ? qq : row - 1); i < iq - 1; i++) R[ridx(row, i)] = R[ridx(row, i + 1)];
-            if (tid == 0) {
-                for (int i = qq; i < iq - 1; i++) {
-                    A[i] = A[i + 1];
-                    u[i] = u[i + 1];
+                for (int i0 = (qq > row - 1 ? qq : row - 1); i0 < iq - 1; i0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; q8++) v[q8] = R[ridx(row, min(i0 + q8, iq - 2) + 1)];
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; q8++)
+                        if (i0 + q8 < iq - 1) R[ridx(row, i0 + q8)] = v[q8];
                 }
-                A[iq - 1] = A[iq];
-                u[iq - 1] = u[iq];
+            // shift A and u: chunks of T entries, each read, then (after a barrier) written
+            for (int c0 = qq; c0 < iq; c0 += T) {
+                const int i = c0 + tid;
+                int av = 0;
+                double uv = 0.0;
+                if (i < iq) {
+                    av = A[i + 1];
+                    uv = u[i + 1];
+                }
+                __syncthreads();
+                if (i < iq) {
+                    A[i] = av;
+                    u[i] = uv;
+                }
+            }
+            if (tid == 0) {
                 A[iq] = 0;
                 u[iq] = 0.0;
             }
@@ -321,7 +390,11 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                                                            __builtin_amdgcn_readlane(__double2loint(tsel), j & 63));
                         const double bj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bsel), j & 63),
                                                            __builtin_amdgcn_readlane(__double2loint(bsel), j & 63));
-                        const double h = distance(tj, bj);
+                        // h = hypot(tj, bj) (distance(), eiquadprog.hpp:90-108) and 1/h from one
+                        // chain; cos and sin by multiplication
+                        const double hh = tj * tj + bj * bj;
+                        double h = 0.0, ih = 0.0;
+                        if (hh > 0.0) sqrt_rsqrt(hh, h, ih);
                         if (h == 0.0) {
                             if (lane == 0) {
                                 rc[j] = 1.0;
@@ -335,17 +408,16 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                             top1 = bot1;
                             continue;
                         }
-                        double cc = tj / h, ss = bj / h, hd = h;
+                        double cc = tj * ih, ss = bj * ih, hd = h;
                         if (cc < 0.0) {
                             cc = -cc;
                             ss = -ss;
                             hd = -h;
                         }
-                        const double xny = ss / (1.0 + cc);
                         if (lane == 0) {
                             rc[j] = cc;
                             rs[j] = ss;
-                            rx[j] = xny;
+                            rx[j] = 0.0;
                             rb[j] = -cc;
                         }
                         if (k0 == j || k1 == j) {
@@ -353,14 +425,12 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                             R[ridx(j + 1, j)] = 0.0;
                         }
                         if (k0 > j && k0 < iq) {
-                            const double nv = top0 * cc + bot0 * ss;
-                            R[ridx(j, k0)] = nv;
-                            top0 = xny * (top0 + nv) - bot0;
+                            R[ridx(j, k0)] = top0 * cc + bot0 * ss;
+                            top0 = top0 * ss - bot0 * cc;
                         }
                         if (k1 > j && k1 < iq) {
-                            const double nv = top1 * cc + bot1 * ss;
-                            R[ridx(j, k1)] = nv;
-                            top1 = xny * (top1 + nv) - bot1;
+                            R[ridx(j, k1)] = top1 * cc + bot1 * ss;
+                            top1 = top1 * ss - bot1 * cc;
                         }
                     }
                 }
@@ -452,12 +522,23 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             }
             for (int i = tid; i < iq; i += T) iai[A[i]] = -1;
             for (int i = tid; i < m; i += T) iaexcl[i] = 1;
-            eval_s(-1);
+            __syncthreads(); // iai, iaexcl
+            eval_all();
             DSTAMP(1);
             falg += 2.0 * mm * nn;
-            double part = 0.0;
-            for (int i = tid; i < m; i += T) part += fmin(0.0, s[i]);
-            const double psi = block_sum(part, red, tid);
+            // the sum of infeasibilities and the most violated row in one exchange; every
+            // thread looks at the rows it has just written itself
+            double psi = 0.0, unused = 0.0, bv0 = DINF;
+            int bi0 = 0x7fffffff;
+            for (int i = tid; i < m; i += T) {
+                const double si = s[i];
+                psi += fmin(0.0, si);
+                if (si < 0.0 && iai[i] != -1 && (si < bv0 || (si == bv0 && i < bi0))) {
+                    bv0 = si;
+                    bi0 = i;
+                }
+            }
+            block_argmin_sums(bv0, bi0, psi, unused, red, redk, tid, flip);
             if (fabs(psi) <= psi_thr) break;
             for (int i = tid; i < iq; i += T) {
                 u_old[i] = u[i];
@@ -465,18 +546,23 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             }
             for (int i = tid; i < n; i += T) x_old[i] = x[i];
             double ss = 0.0;
-            bool restart;
+            bool restart, first = true;
             do { // step 2 (l2)
                 restart = false;
-                __syncthreads();
-                double bv = DINF;
-                int bi = 0x7fffffff;
-                for (int i = tid; i < m; i += T)
-                    if (s[i] < ss && iai[i] != -1 && iaexcl[i] && (s[i] < bv || (s[i] == bv && i < bi))) {
-                        bv = s[i];
-                        bi = i;
-                    }
-                block_argmin(bv, bi, red, redk, tid);
+                double bv = bv0;
+                int bi = bi0;
+                if (!first) { // after a degenerate addition: iaexcl and iai have changed
+                    __syncthreads();
+                    bv = DINF;
+                    bi = 0x7fffffff;
+                    for (int i = tid; i < m; i += T)
+                        if (s[i] < ss && iai[i] != -1 && iaexcl[i] && (s[i] < bv || (s[i] == bv && i < bi))) {
+                            bv = s[i];
+                            bi = i;
+                        }
+                    block_argmin(bv, bi, red, redk, tid, flip);
+                }
+                first = false;
                 DSTAMP(2);
                 if (bv < ss) {
                     ss = bv;
@@ -528,11 +614,18 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     if constexpr (LDSJ) {
                         // one thread per column; the odd leading dimension keeps the lanes on
                         // different banks
+                        // np is zero beyond the knot of row ip on each axis, and adding those
+                        // exact zeros changes nothing: the sums stop there
+                        const int kz = SLACK ? n - 1 : rowK(ip);
                         for (int j = tid; j < n; j += T) {
                             const double *col = J + (size_t)j * ldj;
                             double acc = 0.0;
 #pragma unroll 8
-                            for (int k = 0; k < n; k++) acc += col[k] * np[k];
+                            for (int k = 0; k <= kz; k++) acc += col[k] * np[k];
+                            if constexpr (POLY) {
+#pragma unroll 8
+                                for (int k = N; k <= N + kz; k++) acc += col[k] * np[k];
+                            }
                             d[j] = acc;
                         }
                     } else {
@@ -547,7 +640,10 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     __syncthreads();
                     DSTAMP(3);
                     // z = J2 d2 : one thread per row
-                    for (int row = tid; row < n; row += T) {
+                    // (LDS variant: wave 0 goes straight to the back substitution, which is the
+                    // longer chain, and the other waves share the rows)
+                    for (int row = LDSJ ? tid - 64 : tid; row < n; row += LDSJ ? T - 64 : T) {
+                        if (row < 0) break;
                         double acc = 0.0;
 #pragma unroll 8
                         for (int j = iq; j < n; j++) acc += J[(size_t)j * ldj + row] * d[j];
@@ -566,7 +662,10 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                             const double iv1 = lane + 64 < iq ? 1.0 / R[ridx(lane + 64, lane + 64)] : 0.0;
                             // eight columns of R per group: their loads are issued together, the
                             // chain then runs from registers
-                            for (int k0 = iq - 1; k0 >= 0; k0 -= 8) {
+                            // HI: the group touches columns >= 64, whose rows need the second
+                            // register of each lane; below that only r0 takes part
+                            auto group = [&](int k0, auto hi) {
+                                constexpr bool HI = decltype(hi)::value;
                                 double c0v[8], c1v[8];
 #pragma unroll
                                 for (int q8 = 0; q8 < 8; q8++) {
@@ -575,14 +674,16 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                                     // afterwards: no branch around the load
                                     const int kk = k >= 0 ? k : 0;
                                     const double a0 = R[ridx(lane < kk ? lane : kk, kk)];
-                                    const double a1 = R[ridx(lane + 64 < kk ? lane + 64 : kk, kk)];
                                     // the reciprocal pivot goes into the column here, off the chain
-                                    const double ivsel = kk >= 64 ? iv1 : iv0;
+                                    const double ivsel = HI && kk >= 64 ? iv1 : iv0;
                                     const double inv = __hiloint2double(
                                         __builtin_amdgcn_readlane(__double2hiint(ivsel), kk & 63),
                                         __builtin_amdgcn_readlane(__double2loint(ivsel), kk & 63));
                                     c0v[q8] = (k >= 0 && lane < k) ? a0 * inv : 0.0;
-                                    c1v[q8] = (k >= 0 && lane + 64 < k) ? a1 * inv : 0.0;
+                                    if constexpr (HI) {
+                                        const double a1 = R[ridx(lane + 64 < kk ? lane + 64 : kk, kk)];
+                                        c1v[q8] = (k >= 0 && lane + 64 < k) ? a1 * inv : 0.0;
+                                    }
                                 }
                                 // keep the loads of the group ahead of the chain (the scheduler would
                                 // otherwise sink each load next to its use and serialise on LDS latency)
@@ -594,15 +695,18 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                                 for (int q8 = 0; q8 < 8; q8++) {
                                     const int k = k0 - q8;
                                     if (k >= 0) {
-                                        const double asel = k >= 64 ? r1 : r0;
+                                        const double asel = HI && k >= 64 ? r1 : r0;
                                         const double ak = __hiloint2double(
                                             __builtin_amdgcn_readlane(__double2hiint(asel), k & 63),
                                             __builtin_amdgcn_readlane(__double2loint(asel), k & 63));
                                         r0 = fma(-c0v[q8], ak, r0);
-                                        r1 = fma(-c1v[q8], ak, r1);
+                                        if constexpr (HI) r1 = fma(-c1v[q8], ak, r1);
                                     }
                                 }
-                            }
+                            };
+                            int k0 = iq - 1;
+                            for (; k0 >= 64; k0 -= 8) group(k0, std::true_type{});
+                            for (; k0 >= 0; k0 -= 8) group(k0, std::false_type{});
                             r0 *= iv0;
                             r1 *= iv1;
                             if (lane < iq) r[lane] = r0;
@@ -632,15 +736,13 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                                 kmin = k;
                             }
                         }
-                    block_argmin(t1, kmin, red, redk, tid);
-                    const int l = t1 < DINF ? A[kmin] : 0;
-                    double pz = 0.0, pn = 0.0;
+                    double zz = 0.0, zn = 0.0;
                     for (int i = tid; i < n; i += T) {
-                        pz += z[i] * z[i];
-                        pn += z[i] * np[i];
+                        zz += z[i] * z[i];
+                        zn += z[i] * np[i];
                     }
-                    const double zz = block_sum(pz, red, tid);
-                    const double zn = block_sum(pn, red, tid);
+                    block_argmin_sums(t1, kmin, zz, zn, red, redk, tid, flip);
+                    const int l = t1 < DINF ? A[kmin] : 0;
                     DSTAMP(6);
                     const double t2 = fabs(zz) > EPS ? -s[ip] / zn : DINF;
                     const double t = fmin(t1, t2);
@@ -683,7 +785,6 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                             // rotation of (j-1, j): cc = d[j-1], ss = value carried at j
                             const double h = suf[j - 1];
                             if (h == 0.0) {
-                                rx[j] = DINF;
                                 rc[j] = 1.0;
                                 rs[j] = 0.0;
                                 rb[j] = 1.0;
@@ -696,7 +797,6 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                                 }
                                 rc[j] = cc;
                                 rs[j] = sv;
-                                rx[j] = sv / (1.0 + cc);
                                 rb[j] = -cc;
                             }
                         }
@@ -775,7 +875,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     DSTAMP(6);
                     delete_constraint(l);
                     DSTAMP(8);
-                    eval_s(ip);
+                    eval_one(ip);
                     DSTAMP(1);
                 }
             } while (restart);
@@ -807,7 +907,12 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
         if (!solved)
             for (int i = tid; i < n; i += T) x[i] = 0.0;
         __syncthreads();
-        eval_s(-1);
+        eval_all();
+        for (int k = tid; k < N; k += T) {
+            zx[k] = ((rc[k] + rs[k]) + rx[k]) + suf[k];
+            zy[k] = POLY ? ((rc[N + k] + rs[N + k]) + rx[N + k]) + suf[N + k] : 0.0;
+        }
+        __syncthreads();
         if constexpr (SLACK) {
             if (out.slacks)
                 for (int i = tid; i < 2 * N; i += T) out.slacks[(size_t)inst * 2 * N + i] = x[N + i];
@@ -869,8 +974,8 @@ __global__ void list_all_kernel(int *list, int *count, int B) {
 
 size_t dense_lds_bytes(const DevSetup &sd, bool ldsj) {
     const size_t N = sd.N, n = sd.nvar, m = sd.m;
-    size_t doubles = 5 * n + 3 * (n + 1) + 3 * n + (n + 1) + m + 5 * N + (size_t)sd.nphase * 14 + 4;
-    size_t ints = 4 + 2 * (n + 1) + 2 * m;
+    size_t doubles = 5 * n + 3 * (n + 1) + 3 * n + (n + 1) + m + 5 * N + (size_t)sd.nphase * 14 + 2 * RED_D;
+    size_t ints = 2 * RED_I + 2 * (n + 1) + 2 * m;
     size_t bytes = doubles * 8 + ints * 4 + 64;
     if (ldsj) bytes += (n * (n | 1) + n * (n + 3) / 2 + 2) * 8;
     return bytes;
