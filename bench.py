@@ -103,6 +103,23 @@ class CoupledWorkload:
                 "number_of_steps": 20, "variables": 400, "constraints": self.pl.num_constraints,
                 "weights": {"R": 0.01, "Q": 1.0}, "seed": batches.SEED}
 
+    def host_buffers(self, steps=5):
+        """The same batch through the host-pointer entry point: inputs from and all outputs
+        back to host memory over PCIe inside the timed region (caller-owned arrays, reused)."""
+        i = {k: (v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)) for k, v in self.inputs.items()}
+        args = (i["x0"], i["y0"], i["speed"], i["feet_x"], i["feet_y"], i["swing0"])
+        res = {"unit": self.unit, "entry_point": "mpcb_solve_coupled, every output copied back"}
+        for kind in ("pageable", "pinned"):
+            out = self.pl.host_output_arrays(self.B, P.ALL_OUTPUTS, pinned=kind == "pinned")
+            self.pl.solve_coupled_host(*args, out=out)
+            t = time.perf_counter()
+            for _ in range(steps):
+                self.pl.solve_coupled_host(*args, out=out)
+            dt = (time.perf_counter() - t) / steps
+            res[kind] = {"value": self.B / dt, "ms_per_step": dt * 1e3}
+        res["bytes_per_step"] = int(sum(a.nbytes for a in out.values()) + sum(a.nbytes for a in args))
+        return res
+
     def cpu_baseline(self, threads, sample):
         from oracle import oracle as O
         p = O.params(self.N, R=0.01, Q=1.0, Qs=100.0, height=0.5, dense=1, iter_cap=0)
@@ -390,6 +407,8 @@ def main():
         }
         if epilogue is not None:
             line["epilogue_best_cost"] = epilogue
+        if world == 1 and hasattr(wl, "host_buffers"):
+            line["host_buffers"] = wl.host_buffers()
         if hasattr(wl, "feasible_subset"):
             line["feasible_subset"] = wl.feasible_subset()
         prof, prof_file = measured_profile(args.workload)

@@ -43,6 +43,10 @@ struct mpcb_handle_s {
     int list_capacity = 0;   // entries ws.list can hold
     int dense_blocks = 0;    // slots of ws.J / ws.R
     std::vector<void *> dev_allocs;
+    // device arena of the host-pointer entry points: grown when a batch needs more, kept
+    // between calls (so they neither allocate nor free in steady state)
+    void *stage_dev = nullptr;
+    size_t stage_bytes = 0;
 };
 
 namespace {
@@ -69,17 +73,40 @@ struct DeviceGuard {
 };
 
 // Scratch copies for the host-pointer entry points.
+// Device copies of host arrays, carved out of the handle's arena.  The staging sequence of an
+// entry point runs twice: a dry pass that only adds up the sizes, commit() (which grows the
+// arena if needed), then the pass that hands out the slices and copies the inputs.
 struct Staging {
-    std::vector<void *> bufs;
-    ~Staging() {
-        for (void *p : bufs) (void)hipFree(p);
+    mpcb_handle h;
+    bool dry = true;
+    size_t need = 0, used = 0;
+    explicit Staging(mpcb_handle handle) : h(handle) {}
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    int commit() {
+        if (need > h->stage_bytes) {
+            if (h->stage_dev) HIP_TRY(hipFree(h->stage_dev));
+            h->stage_dev = nullptr;
+            h->stage_bytes = 0;
+            HIP_TRY(hipMalloc(&h->stage_dev, need));
+            h->stage_bytes = need;
+        }
+        dry = false;
+        used = 0;
+        return 0;
+    }
+    template <class T> T *slice(size_t n) {
+        T *p = reinterpret_cast<T *>(static_cast<char *>(h->stage_dev) + used);
+        used += padded(n * sizeof(T));
+        return p;
     }
     template <class T> int in(const T *host, size_t n, const T **dev) {
         *dev = nullptr;
         if (!host || !n) return 0;
-        T *p = nullptr;
-        HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
-        bufs.push_back(p);
+        if (dry) {
+            need += padded(n * sizeof(T));
+            return 0;
+        }
+        T *p = slice<T>(n);
         HIP_TRY(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
         *dev = p;
         return 0;
@@ -87,10 +114,11 @@ struct Staging {
     template <class T> int out(T *host, size_t n, T **dev) {
         *dev = nullptr;
         if (!host || !n) return 0;
-        T *p = nullptr;
-        HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
-        bufs.push_back(p);
-        *dev = p;
+        if (dry) {
+            need += padded(n * sizeof(T));
+            return 0;
+        }
+        *dev = slice<T>(n);
         return 0;
     }
 };
@@ -260,6 +288,7 @@ void mpcb_destroy(mpcb_handle h) {
     {
         DeviceGuard guard(h->params.device);
         for (void *p : h->dev_allocs) (void)hipFree(p);
+        if (h->stage_dev) (void)hipFree(h->stage_dev);
     }
     delete h;
 }
@@ -427,13 +456,16 @@ int mpcb_solve_unconstrained(mpcb_handle h, int32_t B, const double *x0, const d
                              const mpcb_outputs *out) {
     if (!h || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
     DeviceGuard guard(h->params.device);
-    Staging st;
+    Staging st(h);
     const double *dx0, *dz;
     int rc;
     const size_t b = (size_t)B, N = (size_t)h->hs.N;
-    if ((rc = st.in(x0, b * 3, &dx0)) || (rc = st.in(zmp_ref, b * N, &dz))) return rc;
     mpcb_outputs dout;
-    if ((rc = stage_outputs(st, *out, dout, b, N))) return rc;
+    auto stage = [&]() -> int {
+        if ((rc = st.in(x0, b * 3, &dx0)) || (rc = st.in(zmp_ref, b * N, &dz))) return rc;
+        return stage_outputs(st, *out, dout, b, N);
+    };
+    if ((rc = stage()) || (rc = st.commit()) || (rc = stage())) return rc;
     if ((rc = mpcb_solve_unconstrained_device(h, B, dx0, dz, &dout, nullptr))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     if ((rc = fetch_outputs(*out, dout, b, N))) return rc;
@@ -443,20 +475,23 @@ int mpcb_solve_unconstrained(mpcb_handle h, int32_t B, const double *x0, const d
 int mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, const mpcb_outputs *out) {
     if (!h || !in || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
     DeviceGuard guard(h->params.device);
-    Staging st;
+    Staging st(h);
     mpcb_coupled_inputs di;
     std::memset(&di, 0, sizeof(di));
     int rc;
     const size_t b = (size_t)B, N = (size_t)h->hs.N;
-    if ((rc = st.in(in->x0, b * 3, &di.x0)) || (rc = st.in(in->y0, b * 3, &di.y0)) ||
-        (rc = st.in(in->speed, b * 2, &di.speed)) || (rc = st.in(in->feet_x, b * 4, &di.feet_x)) ||
-        (rc = st.in(in->feet_y, b * 4, &di.feet_y)) || (rc = st.in(in->swing0, b, &di.swing0)) ||
-        (rc = st.in(in->com0, b * 2, &di.com0)) ||
-        (rc = st.in(in->rows_pqr, b * (size_t)h->hs.m * 3, &di.rows_pqr)) ||
-        (rc = st.in(in->zref_phase, b * (size_t)h->hs.nphase * 2, &di.zref_phase)))
-        return rc;
     mpcb_outputs dout;
-    if ((rc = stage_outputs(st, *out, dout, b, N))) return rc;
+    auto stage = [&]() -> int {
+        if ((rc = st.in(in->x0, b * 3, &di.x0)) || (rc = st.in(in->y0, b * 3, &di.y0)) ||
+            (rc = st.in(in->speed, b * 2, &di.speed)) || (rc = st.in(in->feet_x, b * 4, &di.feet_x)) ||
+            (rc = st.in(in->feet_y, b * 4, &di.feet_y)) || (rc = st.in(in->swing0, b, &di.swing0)) ||
+            (rc = st.in(in->com0, b * 2, &di.com0)) ||
+            (rc = st.in(in->rows_pqr, b * (size_t)h->hs.m * 3, &di.rows_pqr)) ||
+            (rc = st.in(in->zref_phase, b * (size_t)h->hs.nphase * 2, &di.zref_phase)))
+            return rc;
+        return stage_outputs(st, *out, dout, b, N);
+    };
+    if ((rc = stage()) || (rc = st.commit()) || (rc = stage())) return rc;
     if ((rc = mpcb_solve_coupled_device(h, B, &di, &dout, nullptr))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     if ((rc = fetch_outputs(*out, dout, b, N))) return rc;
@@ -467,14 +502,17 @@ int mpcb_solve_box(mpcb_handle h, int32_t B, const double *x0, const double *zmi
                    const mpcb_outputs *out) {
     if (!h || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
     DeviceGuard guard(h->params.device);
-    Staging st;
+    Staging st(h);
     const double *dx0, *dmin, *dmax;
     int rc;
     const size_t b = (size_t)B, N = (size_t)h->hs.N;
-    if ((rc = st.in(x0, b * 3, &dx0)) || (rc = st.in(zmin, b * N, &dmin)) || (rc = st.in(zmax, b * N, &dmax)))
-        return rc;
     mpcb_outputs dout;
-    if ((rc = stage_outputs(st, *out, dout, b, N))) return rc;
+    auto stage = [&]() -> int {
+        if ((rc = st.in(x0, b * 3, &dx0)) || (rc = st.in(zmin, b * N, &dmin)) || (rc = st.in(zmax, b * N, &dmax)))
+            return rc;
+        return stage_outputs(st, *out, dout, b, N);
+    };
+    if ((rc = stage()) || (rc = st.commit()) || (rc = stage())) return rc;
     if ((rc = mpcb_solve_box_device(h, B, dx0, dmin, dmax, &dout, nullptr))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     if ((rc = fetch_outputs(*out, dout, b, N))) return rc;

@@ -74,6 +74,8 @@ def load_library():
         lib.mpcb_num_constraints.argtypes = [C.c_void_p]
         lib.mpcb_solve_coupled_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CoupledInputs),
                                                   C.POINTER(Outputs), C.c_void_p]
+        lib.mpcb_solve_coupled.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CoupledInputs),
+                                           C.POINTER(Outputs)]
         lib.mpcb_solve_box_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_get_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -240,6 +242,54 @@ class BatchedPlanner:
         prepared = self.prepare_coupled(x0, y0, speed, feet_x, feet_y, swing0, com0, rows_pqr,
                                         zref_phase)
         return self.solve_coupled_prepared(prepared, outputs=outputs, stream=stream)
+
+    def host_output_arrays(self, B, outputs=DEFAULT_OUTPUTS, pinned=False):
+        """Host arrays for solve_coupled_host(out=...); pinned=True page-locks them (views of
+        pinned torch tensors), which is what lets the copies run at PCIe speed."""
+        N, res = self.horizon, {}
+        for name in outputs:
+            if name in ("cost", "alg_flops"):
+                shape, dt = (B,), np.float64
+            elif name in ("status", "iters", "n_active"):
+                shape, dt = (B,), np.int32
+            elif name == "active_idx":
+                shape, dt = (B, self.active_stride), np.int32
+            elif name == "multipliers":
+                shape, dt = (B, self.active_stride), np.float64
+            else:
+                shape, dt = (B, N), np.float64
+            if pinned:
+                tdt = self._torch.float64 if dt is np.float64 else self._torch.int32
+                res[name] = self._torch.zeros(shape, dtype=tdt).pin_memory().numpy()
+            else:
+                res[name] = np.zeros(shape, dt)
+        return res
+
+    def solve_coupled_host(self, x0, y0, speed, feet_x, feet_y, swing0, com0=None,
+                           outputs=DEFAULT_OUTPUTS, out=None):
+        """The same call on host memory (numpy in, numpy out) through mpcb_solve_coupled: the
+        library stages inputs and outputs over PCIe itself and returns when they are back.
+        out: arrays from host_output_arrays to fill (reused between calls)."""
+        f64 = np.float64
+        arrs = dict(x0=np.ascontiguousarray(x0, f64), y0=np.ascontiguousarray(y0, f64),
+                    speed=np.ascontiguousarray(speed, f64), feet_x=np.ascontiguousarray(feet_x, f64),
+                    feet_y=np.ascontiguousarray(feet_y, f64),
+                    swing0=np.ascontiguousarray(swing0, np.int32),
+                    com0=None if com0 is None else np.ascontiguousarray(com0, f64))
+        B = arrs["x0"].shape[0]
+        ci = CoupledInputs()
+        for k, a in arrs.items():
+            if a is not None:
+                setattr(ci, k, a.ctypes.data)
+        res = out if out is not None else self.host_output_arrays(B, outputs)
+        o = Outputs()
+        o.active_stride = self.active_stride
+        for name, a in res.items():
+            if a.shape[0] != B or not a.flags.c_contiguous:
+                raise ValueError("output array %s does not fit the batch" % name)
+            setattr(o, name, a.ctypes.data)
+        _check(load_library().mpcb_solve_coupled(self._h, B, C.byref(ci), C.byref(o)))
+        return res
 
     def prepare_box(self, x0, zmin, zmax):
         f64 = self._torch.float64
