@@ -246,6 +246,27 @@ def test_full_batch_properties(P):
     assert np.array_equal(o3["jerk_x"], o["jerk_x"][4000:4032])
 
 
+def test_host_pointer_entry_point_matches_device_path(P):
+    """mpcb_solve_coupled (host arrays; the library stages them in its own device arena) returns
+    bit for bit what mpcb_solve_coupled_device returns, also when a smaller and then a larger
+    batch reuse / regrow the arena, and into page-locked arrays."""
+    N, steps = 200, 20
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
+    for B, pinned in ((48, False), (16, False), (80, True)):
+        bt = batches.coupled_batch(B, first=1000 + B)
+        dev = _np(pl.solve_coupled(**bt))
+        out = pl.host_output_arrays(B, pinned=pinned)
+        host = pl.solve_coupled_host(bt["x0"], bt["y0"], bt["speed"], bt["feet_x"], bt["feet_y"],
+                                     bt["swing0"], out=out)
+        assert host is out
+        for k, v in dev.items():
+            assert np.array_equal(host[k], v), (B, k)
+        assert (host["status"] == 0).all() and host["n_active"].min() >= 1
+    with pytest.raises(ValueError):
+        pl.solve_coupled_host(bt["x0"], bt["y0"], bt["speed"], bt["feet_x"], bt["feet_y"], bt["swing0"],
+                              out=pl.host_output_arrays(B + 1))
+
+
 def test_empty_batch_and_bad_arguments(P):
     pl = P.BatchedPlanner(20, formulation=P.BOX_1D, weight_R=1.0)
     out = pl.solve_box(np.zeros((0, 3)), np.zeros((0, 20)), np.zeros((0, 20)))
