@@ -201,6 +201,7 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
     std::memcpy(ds.F, hs.F, sizeof(ds.F));
     ds.psi_thr = (double)hs.m * 2.220446049250313e-16 * hs.c1 * hs.c2 * 100.0;
     ds.traceG1 = hs.traceG1;
+    ds.Ts = params->Ts;
     std::memcpy(ds.hip, params->hip_offsets, sizeof(ds.hip));
     if ((rc = upload_to(h, hs.S, &ds.S)) || (rc = upload_to(h, hs.Wt, &ds.Wt)) ||
         (rc = upload_to(h, hs.Sc, &ds.Sc)) || (rc = upload_to(h, hs.Sv, &ds.Sv)) ||

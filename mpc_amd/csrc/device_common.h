@@ -69,6 +69,18 @@ __device__ __forceinline__ double wave_sum(double v) {
     return lane63(v);
 }
 
+// Inclusive prefix sum over the lanes (lane i receives v_0 + ... + v_i): shifts inside each row
+// of 16 lanes (lanes without a source add 0), then the totals of the rows before.
+__device__ __forceinline__ double wave_scan(double v) {
+    v += dpp_f64<0x111, 0xF>(0.0, v); // row_shr:1
+    v += dpp_f64<0x112, 0xF>(0.0, v); // row_shr:2
+    v += dpp_f64<0x114, 0xF>(0.0, v); // row_shr:4
+    v += dpp_f64<0x118, 0xF>(0.0, v); // row_shr:8
+    v += dpp_f64<0x142, 0xA>(0.0, v); // row_bcast15 -> rows 1, 3
+    v += dpp_f64<0x143, 0xC>(0.0, v); // row_bcast31 -> rows 2, 3
+    return v;
+}
+
 // NaN-ignoring minimum (fmin), like the reference's `<` comparisons that never pick a NaN.
 __device__ __forceinline__ double wave_min(double v) {
     v = fmin(v, dpp_perm_f64<0xB1>(v));

@@ -28,6 +28,7 @@ struct DevSetup {
     double F[16];
     double psi_thr;                   // m * eps * c1 * c2 * 100 (eiquadprog.hpp:267)
     double traceG1;
+    double Ts;                        // sample time of the prediction model
     double hip[8];
     long long *dbg;                   // cycle stamps (diagnostic builds only), else NULL
 };

@@ -784,19 +784,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
         nresp = iq + 1;
         wsync();
     }
-    auto respond = [&](const double *K, const double *M, const double *Mp, double *ox, double *oy) {
-        if (!ox && !oy) return;
-        double vx[NPL], vy[NPL];
-#pragma unroll
-        for (int c = 0; c < NPL; c++) {
-            const double *k4 = K + (size_t)kc[c] * 4;
-            vx[c] = k4[0] * wx[0] + k4[1] * wx[1] + k4[2] * wx[2] + k4[3] * wx[3];
-            vy[c] = k4[0] * wy[0] + k4[1] * wy[1] + k4[2] * wy[2] + k4[3] * wy[3];
-        }
-        if constexpr (POLY) {
-            if (Mp) accum_phases(Mp, vx, vy);
-        }
-        accum_rows(M, nresp, vx, vy);
+    auto store_pair = [&](double *ox, double *oy, const double *vx, const double *vy) {
 #pragma unroll
         for (int c = 0; c < NPL; c++)
             if (kn[c] < N) {
@@ -805,10 +793,105 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
             }
     };
     STAMP(12);
-    respond(sd.Kx, sd.Wt, sd.Wp, out.jerk_x, out.jerk_y);
-    STAMP(13);
-    respond(sd.Kc, sd.Sc, sd.Scp, out.com_x, out.com_y);
-    respond(sd.Kv, sd.Sv, sd.Svp, out.com_xd, out.com_yd);
+    const bool want_com = out.com_x || out.com_y || out.com_xd || out.com_yd;
+    if (out.jerk_x || out.jerk_y || want_com) {
+        // jerk = unconstrained response + response to the multipliers
+        double jx[NPL], jy[NPL];
+#pragma unroll
+        for (int c = 0; c < NPL; c++) {
+            const double *k4 = sd.Kx + (size_t)kc[c] * 4;
+            jx[c] = k4[0] * wx[0] + k4[1] * wx[1] + k4[2] * wx[2] + k4[3] * wx[3];
+            jy[c] = k4[0] * wy[0] + k4[1] * wy[1] + k4[2] * wy[2] + k4[3] * wy[3];
+        }
+        if constexpr (POLY) {
+            if (sd.Wp) accum_phases(sd.Wp, jx, jy);
+        }
+        accum_rows(sd.Wt, nresp, jx, jy);
+        store_pair(out.jerk_x, out.jerk_y, jx, jy);
+        STAMP(13);
+        if (want_com) {
+            // computeCOMtrajectory (MPCPlanner.cpp:196-209) without its N x N products.  The
+            // triple integrator's response to the jerk is a convolution with a quadratic in
+            // the knot distance p = k - j:  position T^3 (1/6 + p/2 + p^2/2), velocity
+            // T^2 (1/2 + p).  With the running moments S0 = sum u_j, S1 = sum j u_j,
+            // S2 = sum j^2 u_j over j <= k:
+            //   sum p u_j = k S0 - S1,   sum p^2 u_j = k (k S0 - S1) - (k S1 - S2).
+            // For this the jerk is re-dealt through LDS (the factor's storage is free by now)
+            // so that every lane holds NPL consecutive knots: the moments run serially inside
+            // a lane and need one prefix scan across the lanes each.
+            double *sx = W.Rinv, *sy = W.Rinv + 64 * NPL;
+            static_assert(2 * 64 * NPL <= QL * LDI, "jerk exchange does not fit the factor storage");
+            wsync();
+#pragma unroll
+            for (int c = 0; c < NPL; c++) {
+                sx[lane + 64 * c] = jx[c];
+                if constexpr (POLY) sy[lane + 64 * c] = jy[c];
+            }
+            wsync();
+            const int k0 = NPL * lane;
+            const double T1 = sd.Ts, T2 = T1 * T1, T3 = T2 * T1;
+            auto integrate = [&](const double *su, const double *w, double *op, double *ov) {
+                if (!op && !ov) return;
+                double u[NPL], l0[NPL], l1[NPL], l2[NPL];
+#pragma unroll
+                for (int i = 0; i < NPL; i++) u[i] = su[k0 + i];
+                double m0 = 0.0, m1 = 0.0, m2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < NPL; i++) {
+                    const double k = (double)(k0 + i);
+                    m0 += u[i];
+                    m1 = fma(k, u[i], m1);
+                    m2 = fma(k * k, u[i], m2);
+                    l0[i] = m0;
+                    l1[i] = m1;
+                    l2[i] = m2;
+                }
+                // moments of the lanes before this one
+                const double e0 = wave_scan(m0) - m0, e1 = wave_scan(m1) - m1, e2 = wave_scan(m2) - m2;
+                double pos[NPL], vel[NPL];
+#pragma unroll
+                for (int i = 0; i < NPL; i++) {
+                    const double k = (double)(k0 + i), tk = (k + 1.0) * T1;
+                    const double S0 = e0 + l0[i], S1 = e1 + l1[i], S2 = e2 + l2[i];
+                    const double lx = fma(k, S0, -S1), mx = fma(k, lx, -fma(k, S1, -S2));
+                    pos[i] = w[0] + tk * (w[1] + 0.5 * tk * w[2]) + T3 * (S0 * (1.0 / 6.0) + 0.5 * (lx + mx));
+                    vel[i] = w[1] + tk * w[2] + T2 * (0.5 * S0 + lx);
+                    if (!solved) {
+                        pos[i] = 0.0;
+                        vel[i] = 0.0;
+                    }
+                }
+                auto store_run = [&](double *o, const double *v) {
+                    if (!o) return;
+                    double *dst = o + (size_t)inst * N + k0;
+                    if ((NPL & 1) == 0 && (reinterpret_cast<size_t>(dst) & 15) == 0) {
+#pragma unroll
+                        for (int i = 0; i + 1 < NPL; i += 2) {
+                            if (k0 + i + 1 < N) *reinterpret_cast<double2 *>(dst + i) = make_double2(v[i], v[i + 1]);
+                            else if (k0 + i < N) dst[i] = v[i];
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NPL; i++)
+                            if (k0 + i < N) dst[i] = v[i];
+                    }
+                };
+                store_run(op, pos);
+                store_run(ov, vel);
+            };
+            integrate(sx, wx, out.com_x, out.com_xd);
+            if constexpr (POLY) {
+                integrate(sy, wy, out.com_y, out.com_yd);
+            } else {
+                // one axis only: the other axis' outputs are identically zero
+                double zero[NPL];
+#pragma unroll
+                for (int c = 0; c < NPL; c++) zero[c] = 0.0;
+                store_pair(nullptr, out.com_y, zero, zero);
+                store_pair(nullptr, out.com_yd, zero, zero);
+            }
+        }
+    }
     STAMP(14);
     if (out.zmp_x || out.zmp_y || out.min_margin) {
         // On a regular exit zx, zy were evaluated at the final multipliers in step 1.
