@@ -283,6 +283,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="nccl (= RCCL) for one rank per GPU; gloo lets several ranks share a GPU "
                          "for rehearsals")
+    ap.add_argument("--host-steps", type=int, default=5,
+                    help="steps of the host-pointer (PCIe-inclusive) side measurement at N=1; 0 = skip")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="instances timed on the host cores (0 disables, -1 = default)")
     args = ap.parse_args()
@@ -407,8 +409,8 @@ def main():
         }
         if epilogue is not None:
             line["epilogue_best_cost"] = epilogue
-        if world == 1 and hasattr(wl, "host_buffers"):
-            line["host_buffers"] = wl.host_buffers()
+        if world == 1 and args.host_steps > 0 and hasattr(wl, "host_buffers"):
+            line["host_buffers"] = wl.host_buffers(args.host_steps)
         if hasattr(wl, "feasible_subset"):
             line["feasible_subset"] = wl.feasible_subset()
         prof, prof_file = measured_profile(args.workload)

@@ -5,6 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mpc_amd import batches, planner as P
 names = ["prologue", "l1 rows", "s eval+psi", "select", "g gather", "d,r", "zn+t1", "add writes (+drop)", "zmp/margin out", "t2,t", "f,u,rho", "-", "scalars/active out", "jerk out", "com,vel out", "-"]
+def makespan(cost, slots):
+    """Greedy list scheduling in the given order: what the hardware dispatcher does."""
+    import heapq
+    h = [0.0] * slots
+    for c in cost:
+        heapq.heappush(h, heapq.heappop(h) + c)
+    return max(h)
 def run(wl, B):
     if wl in ("coupled", "jerk"):
         bt = batches.coupled_batch(B)
@@ -26,6 +33,9 @@ def run(wl, B):
     it = out["iters"].cpu().numpy()
     tot = d.sum(axis=1)
     print(wl, "B", B, "mean cycles/solve %.0f  mean iters %.1f" % (tot.mean(), it.mean()))
+    q = np.percentile(tot, [50, 90, 99, 100])
+    print("  cycles/solve percentiles 50/90/99/100: %.0f %.0f %.0f %.0f; iters max %d; simulated makespan on 2048 slots"
+          " in dispatch order: %.0f cycles vs ideal %.0f" % (q[0], q[1], q[2], q[3], it.max(), makespan(tot, 2048), tot.sum() / 2048))
     for i, n in enumerate(names[:15]):
         print("  %-14s %9.0f cycles  %5.1f%%" % (n, d[:, i].mean(), 100 * d[:, i].sum() / tot.sum()))
 run("coupled", 8192)
