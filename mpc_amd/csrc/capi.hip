@@ -208,7 +208,6 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
         (rc = upload_to(h, hs.Kx, &ds.Kx)) || (rc = upload_to(h, hs.Kz, &ds.Kz)) ||
         (rc = upload_to(h, hs.Kc, &ds.Kc)) || (rc = upload_to(h, hs.Kv, &ds.Kv)) ||
         (rc = upload_to(h, hs.Sp, &ds.Sp)) || (rc = upload_to(h, hs.Wp, &ds.Wp)) ||
-        (rc = upload_to(h, hs.Scp, &ds.Scp)) || (rc = upload_to(h, hs.Svp, &ds.Svp)) ||
         (rc = upload_to(h, hs.F2, &ds.F2)) || (rc = upload_to(h, hs.F3, &ds.F3)) ||
         (rc = upload_to(h, hs.knot_phase, &ds.knot_phase)) ||
         (rc = upload_to(h, hs.knot_row0, &ds.knot_row0))) {

@@ -23,7 +23,7 @@ struct DevSetup {
     // ZMP-reference formulation only (else NULL): responses to a unit reference on the
     // knots of one phase, [nphase][N], weight Qs folded in; cost terms F2 [4][nphase],
     // F3 [nphase][nphase]
-    const double *Sp, *Wp, *Scp, *Svp, *F2, *F3;
+    const double *Sp, *Wp, *F2, *F3;
     const int *knot_phase, *knot_row0; // [N]
     double F[16];
     double psi_thr;                   // m * eps * c1 * c2 * 100 (eiquadprog.hpp:267)

@@ -343,15 +343,13 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
             // phase's knots).  g0 gains -Qs Zu' zref (MPCPlanner.cpp:731-735).
             const int P = o.nphase;
             const ld Qs = p.weight_Qs;
-            LVec Sp((size_t)P * N, 0), Wp((size_t)P * N, 0), Scp((size_t)P * N, 0), Svp((size_t)P * N, 0);
+            LVec Sp((size_t)P * N, 0), Wp((size_t)P * N, 0);
             LVec F2((size_t)4 * P, 0), F3((size_t)P * P, 0);
             for (int k = 0; k < N; k++) {
                 const int ph = o.knot_phase[k];
                 for (int i = 0; i < N; i++) {
                     Sp[(size_t)ph * N + i] += Qs * S[(size_t)k * N + i];
                     Wp[(size_t)ph * N + i] += Qs * W[(size_t)i * N + k];
-                    Scp[(size_t)ph * N + i] += Qs * Sc[(size_t)i * N + k];
-                    Svp[(size_t)ph * N + i] += Qs * Sv[(size_t)i * N + k];
                 }
                 for (int a = 0; a < 4; a++) {
                     const ld zukx = Kz[(size_t)k * 4 + a] - (a < 3 ? Z.sx[(size_t)k * 3 + a] : 0);
@@ -362,8 +360,6 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
             }
             o.Sp = to_double(Sp);
             o.Wp = to_double(Wp);
-            o.Scp = to_double(Scp);
-            o.Svp = to_double(Svp);
             o.F2 = to_double(F2);
             o.F3 = to_double(F3);
         }

@@ -25,7 +25,7 @@ struct HostSetup {
     std::vector<double> Kx, Kz, Kc, Kv;
     double F[16];         // f_unc = w^T F w per axis
     // ZMP-reference formulation: per-phase responses [nphase][N] and cost terms
-    std::vector<double> Sp, Wp, Scp, Svp, F2, F3;
+    std::vector<double> Sp, Wp, F2, F3;
     double c1 = 0, c2 = 0;   // trace(G), trace(L^-T) of the full Hessian (eiquadprog.hpp:162,176)
     double traceG1 = 0;
     // row bookkeeping of computeSteps / buildPolygonMatrix
