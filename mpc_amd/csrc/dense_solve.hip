@@ -116,8 +116,10 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
     double *u = x_old + n, *u_old = u + (n + 1), *r = u_old + (n + 1);
     // rotation cos / sin / sin/(1+cos) per column, suffix norms; rb = -cos, or +1 where a column
     // pair is left unrotated: (new, carried) = (c t1 + s t2, s t1 + rb t2) then needs no test
-    // rb shares the storage of z: the step direction is dead from the moment x has been
-    // updated until the next pass recomputes it, which is exactly when rotations happen
+    // Without LDS-resident matrices rb shares the storage of z: the step direction is dead from
+    // the moment x has been updated until the next pass recomputes it, which is when rotations
+    // happen.  The LDS variant computes the coefficients of a possible addition while z is still
+    // live (see the pass loop) and gives rb an array of its own behind R.
     double *rc = r + (n + 1), *rs = rc + n, *rx = rs + n, *rb = z, *suf = rx + n;
     double *s = suf + (n + 1);
     double *zx = s + m, *zy = zx + N;
@@ -155,6 +157,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
         if constexpr (LDSJ) {
             J = lds_mats;
             R = lds_mats + (size_t)n * ldj;
+            rb = R + (size_t)n * (n + 3) / 2 + 2;
         } else {
             J = ws.J + (size_t)blockIdx.x * n * n;
             R = ws.R + (size_t)blockIdx.x * n * n;
@@ -512,6 +515,39 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             __syncthreads();
         };
 
+        // Rotation coefficients of add_constraint (eiquadprog.hpp:450-513) for the current d:
+        // the reference's sequential hypot chain over d[n-1], d[n-2], ... is the suffix norm
+        // nu_j = ||d[j..n-1]||, so all rotations come out in parallel.  Threads t0, t0 + nt, ...
+        // of a group that `sync` synchronises.
+        auto add_coefs = [&](int t0, int nt, auto sync) {
+            for (int j = iq + t0; j < n; j += nt) {
+                double acc = 0.0;
+#pragma unroll 8
+                for (int i = n - 1; i >= j; i--) acc += d[i] * d[i];
+                suf[j] = sqrt(acc);
+            }
+            sync();
+            for (int j = iq + 1 + t0; j < n; j += nt) {
+                // rotation of (j-1, j): cc = d[j-1], ss = value carried at j
+                const double h = suf[j - 1];
+                if (h == 0.0) {
+                    rc[j] = 1.0;
+                    rs[j] = 0.0;
+                    rb[j] = 1.0;
+                } else {
+                    double cur = (j == n - 1) ? d[j] : (d[j] < 0.0 ? -suf[j] : suf[j]);
+                    double cc = d[j - 1] / h, sv = cur / h;
+                    if (cc < 0.0) {
+                        cc = -cc;
+                        sv = -sv;
+                    }
+                    rc[j] = cc;
+                    rs[j] = sv;
+                    rb[j] = -cc;
+                }
+            }
+        };
+
         bool done = false;
         DSTAMP(0);
         while (!done) { // step 1 (l1)
@@ -640,14 +676,19 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     __syncthreads();
                     DSTAMP(3);
                     // z = J2 d2 : one thread per row
-                    // (LDS variant: wave 0 goes straight to the back substitution, which is the
-                    // longer chain, and the other waves share the rows)
-                    for (int row = LDSJ ? tid - 64 : tid; row < n; row += LDSJ ? T - 64 : T) {
-                        if (row < 0) break;
-                        double acc = 0.0;
+                    // (LDS variant, n <= 128: wave 0 goes straight to the back substitution, which
+                    // is the longest chain of the pass; waves 1 and 2 share the rows of z; wave 3
+                    // prepares the rotation coefficients of an addition, which is how two passes
+                    // in three end and depends on d alone)
+                    if (!LDSJ || wave == 1 || wave == 2)
+                        for (int row = LDSJ ? tid - 64 : tid; row < n; row += LDSJ ? 128 : T) {
+                            double acc = 0.0;
 #pragma unroll 8
-                        for (int j = iq; j < n; j++) acc += J[(size_t)j * ldj + row] * d[j];
-                        z[row] = acc;
+                            for (int j = iq; j < n; j++) acc += J[(size_t)j * ldj + row] * d[j];
+                            z[row] = acc;
+                        }
+                    if constexpr (LDSJ) {
+                        if (wave == 3) add_coefs(lane, 64, [] { wsync(); });
                     }
                     DSTAMP(4);
                     // r = R^-1 d1 (back substitution, column oriented)
@@ -773,34 +814,10 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                         // add_constraint (eiquadprog.hpp:450-513)
                         falg += 6.0 * nn * (nn - iq - 1);
                         DSTAMP(10);
-                        // suffix norms nu_j = ||d[j..n-1]||
-                        for (int j = iq + tid; j < n; j += T) {
-                            double acc = 0.0;
-#pragma unroll 8
-                            for (int i = n - 1; i >= j; i--) acc += d[i] * d[i];
-                            suf[j] = sqrt(acc);
+                        if constexpr (!LDSJ) {
+                            add_coefs(tid, T, [] { __syncthreads(); });
+                            __syncthreads();
                         }
-                        __syncthreads();
-                        for (int j = iq + 1 + tid; j < n; j += T) {
-                            // rotation of (j-1, j): cc = d[j-1], ss = value carried at j
-                            const double h = suf[j - 1];
-                            if (h == 0.0) {
-                                rc[j] = 1.0;
-                                rs[j] = 0.0;
-                                rb[j] = 1.0;
-                            } else {
-                                double cur = (j == n - 1) ? d[j] : (d[j] < 0.0 ? -suf[j] : suf[j]);
-                                double cc = d[j - 1] / h, sv = cur / h;
-                                if (cc < 0.0) {
-                                    cc = -cc;
-                                    sv = -sv;
-                                }
-                                rc[j] = cc;
-                                rs[j] = sv;
-                                rb[j] = -cc;
-                            }
-                        }
-                        __syncthreads();
                         DSTAMP(11);
                         for (int row = tid; row < n; row += T) {
                             if (n - 1 >= iq + 1) {
@@ -977,7 +994,7 @@ size_t dense_lds_bytes(const DevSetup &sd, bool ldsj) {
     size_t doubles = 5 * n + 3 * (n + 1) + 3 * n + (n + 1) + m + 5 * N + (size_t)sd.nphase * 14 + 2 * RED_D;
     size_t ints = 2 * RED_I + 2 * (n + 1) + 2 * m;
     size_t bytes = doubles * 8 + ints * 4 + 64;
-    if (ldsj) bytes += (n * (n | 1) + n * (n + 3) / 2 + 2) * 8;
+    if (ldsj) bytes += (n * (n | 1) + n * (n + 3) / 2 + 2 + n) * 8;
     return bytes;
 }
 
