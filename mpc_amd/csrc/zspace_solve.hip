@@ -564,6 +564,11 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
             // n_ip' G^-1 n_ip; the load is consumed after the gather of the first pass has been
             // issued, so that the two memory round trips overlap
             const double skk = sd.S[(size_t)kip * N + kip];
+            // g_a = n_a' G^-1 n_ip depends on the pair (a, ip) only: it is gathered once per
+            // candidate, and a drop merely closes the gap (lanes above the dropped position move
+            // down by one) instead of paying another round trip to the table
+            double ga = 0.0;
+            bool have_g = false;
 
             for (;;) { // step 2a (l2a), :306-446
                 passes++;
@@ -574,12 +579,15 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 }
                 falg += 2 * nn * nn + 2 * nn * (nn - iq) + (long long)iq * iq;
                 // g = N_A' G^-1 n_ip ; d = R^-T g (= J1' n_ip) ; r = R^-1 d
-                double ga = 0.0, da = 0.0, ra = 0.0, ua = 0.0;
+                double da = 0.0, ra = 0.0, ua = 0.0;
                 if (lane < iq) {
-                    const int ka = W.wsKS[lane] >> 2;
-                    ga = (W.wsP[lane] * pip + W.wsQ[lane] * qip) * sd.S[(size_t)ka * N + kip];
+                    if (!have_g) {
+                        const int ka = W.wsKS[lane] >> 2;
+                        ga = (W.wsP[lane] * pip + W.wsQ[lane] * qip) * sd.S[(size_t)ka * N + kip];
+                    }
                     ua = W.wsU[lane];
                 }
+                have_g = true;
                 W.g[lane < QL ? lane : QL] = ga;
                 wsync();
                 const double mii = ufirst((pip * pip + qip * qip) * skk);
@@ -663,6 +671,10 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                         falg += 6 * nn * cdrop + 3 * cdrop * (cdrop - 1);
                     }
                     drop_constraint(W, lane, iq, apos);
+                    {
+                        const double up = dpp_f64<0x130, 0xF>(0.0, ga); // wave_shl:1 -- value of lane + 1
+                        ga = lane >= apos ? up : ga;
+                    }
                     continue;
                 }
                 // step in primal and dual space (:377-382)
@@ -746,6 +758,10 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                     falg += 6 * nn * cdrop + 3 * cdrop * (cdrop - 1);
                 }
                 drop_constraint(W, lane, iq, apos);
+                {
+                    const double up = dpp_f64<0x130, 0xF>(0.0, ga); // wave_shl:1 -- value of lane + 1
+                    ga = lane >= apos ? up : ga;
+                }
             }
         } while (restart);
         STAMP(7);
