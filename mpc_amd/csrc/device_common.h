@@ -158,16 +158,11 @@ __device__ __forceinline__ double distance(double a, double b) {
 // tab[(myph*4 + edge)*3 ..].  speed = userSpeed, used as per-step displacement.
 // cref (may be NULL) receives the centroid of the phase's stance feet, the ZMP
 // reference of computeCentroid (MPCPlanner.cpp:1106-1130), at cref[2*myph .. +1].
-__device__ inline void polygon_phase(const DevSetup &sd, const DevIn &in, int inst, double spx,
-                                     double spy, int myph, double *tab, double *cref) {
-    const double *pfx = in.feet_x + (size_t)inst * 4, *pfy = in.feet_y + (size_t)inst * 4;
-    double c0x = 0.0, c0y = 0.0;
-    if (in.com0) {
-        c0x = in.com0[(size_t)inst * 2];
-        c0y = in.com0[(size_t)inst * 2 + 1];
-    }
+// pfx, pfy: the four initial feet; (c0x, c0y): initialCoM; swing0: swing_leg_index.
+__device__ inline void polygon_phase(const DevSetup &sd, const double *pfx, const double *pfy, double c0x,
+                                     double c0y, int swing0, double spx, double spy, int myph, double *tab,
+                                     double *cref) {
     const bool correct = !(c0x == 0.0 && c0y == 0.0); // initialCoM.isZero(0), :1231
-    const int swing0 = in.swing0[inst];
     // schedule LF, RH, RF, LH (:1197); setCurrentSwing (FootScheduler.h:33-43)
     int cur = 0;
     if (swing0 == 3) cur = 1;
@@ -203,14 +198,19 @@ __device__ inline void polygon_phase(const DevSetup &sd, const DevIn &in, int in
         const int first = (pos - cur) & 3;                              // index of the leg's first swing
         nsw[l] = taken > first ? (taken - first + 3) >> 2 : 0;
     }
-    for (int j = 0; j < (sd.steps + 3) >> 2; j++) {
+    // (a swing that has not happened adds an exact zero: no branches in the replay)
+#pragma unroll
+    for (int l = 0; l < 4; l++) { // the first swing may carry the CoM correction (:1266-1280)
+        const bool on = nsw[l] > 0;
+        fx[l] += on ? (flag[l] ? corrx[l] : spx) : 0.0;
+        fy[l] += on ? (flag[l] ? corry[l] : spy) : 0.0;
+    }
+    for (int j = 1; j < (sd.steps + 3) >> 2; j++) {
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-            if (j < nsw[l]) {
-                const bool fl = flag[l] && j == 0; // :1266-1280
-                fx[l] += fl ? corrx[l] : spx;
-                fy[l] += fl ? corry[l] : spy;
-            }
+            const bool on = j < nsw[l];
+            fx[l] += on ? spx : 0.0;
+            fy[l] += on ? spy : 0.0;
         }
     }
 #pragma unroll
@@ -274,6 +274,18 @@ __device__ inline void polygon_phase(const DevSetup &sd, const DevIn &in, int in
             t[2] = r;
         }
     }
+}
+
+// The same with the instance's feet, initial CoM and swing leg read from the batch inputs.
+__device__ inline void polygon_phase(const DevSetup &sd, const DevIn &in, int inst, double spx,
+                                     double spy, int myph, double *tab, double *cref) {
+    double c0x = 0.0, c0y = 0.0;
+    if (in.com0) {
+        c0x = in.com0[(size_t)inst * 2];
+        c0y = in.com0[(size_t)inst * 2 + 1];
+    }
+    polygon_phase(sd, in.feet_x + (size_t)inst * 4, in.feet_y + (size_t)inst * 4, c0x, c0y, in.swing0[inst], spx,
+                  spy, myph, tab, cref);
 }
 
 // Cost of the unconstrained minimiser, f = 1/2 g0'x (eiquadprog.hpp:191), for one axis:

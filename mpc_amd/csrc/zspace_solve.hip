@@ -195,22 +195,51 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
         kc[c] = kn[c] < N ? kn[c] : N - 1;
     }
 
-    // ---- instance inputs (wave-uniform addresses) -------------------------
+    // ---- instance inputs ---------------------------------------------------
+    // Every scalar input of the instance is fetched by ONE vector load (a lane per value) and
+    // handed round by readlane: as wave-uniform scalar loads they were issued one array after
+    // the other, each a full miss to HBM at the head of the kernel.
     double wx[4], wy[4];
+    double feetx[4] = {0, 0, 0, 0}, feety[4] = {0, 0, 0, 0}, com0x = 0.0, com0y = 0.0;
+    int swing_first = 0;
     {
-        const double *px = in.x0 + (size_t)inst * 3;
-        wx[0] = px[0];
-        wx[1] = px[1];
-        wx[2] = px[2];
+        const double *src = nullptr;
+        if (lane < 3) src = in.x0 + (size_t)inst * 3 + lane;
+        if constexpr (POLY) {
+            if (lane >= 3 && lane < 6) src = in.y0 + (size_t)inst * 3 + (lane - 3);
+            if (lane >= 6 && lane < 8) src = in.speed + (size_t)inst * 2 + (lane - 6);
+            if constexpr (!ROWS) {
+                if (lane >= 8 && lane < 12) src = in.feet_x + (size_t)inst * 4 + (lane - 8);
+                if (lane >= 12 && lane < 16) src = in.feet_y + (size_t)inst * 4 + (lane - 12);
+                if (lane >= 16 && lane < 18 && in.com0) src = in.com0 + (size_t)inst * 2 + (lane - 16);
+            }
+        }
+        int sw = 0;
+        if constexpr (POLY && !ROWS) {
+            if (lane == 18) sw = in.swing0[inst];
+        }
+        const double v = src ? *src : 0.0;
+        wx[0] = lane_bcast(v, 0);
+        wx[1] = lane_bcast(v, 1);
+        wx[2] = lane_bcast(v, 2);
         wx[3] = 0.0;
         wy[0] = wy[1] = wy[2] = wy[3] = 0.0;
         if constexpr (POLY) {
-            const double *py = in.y0 + (size_t)inst * 3;
-            wy[0] = py[0];
-            wy[1] = py[1];
-            wy[2] = py[2];
-            wx[3] = in.speed[(size_t)inst * 2];
-            wy[3] = in.speed[(size_t)inst * 2 + 1];
+            wy[0] = lane_bcast(v, 3);
+            wy[1] = lane_bcast(v, 4);
+            wy[2] = lane_bcast(v, 5);
+            wx[3] = lane_bcast(v, 6);
+            wy[3] = lane_bcast(v, 7);
+            if constexpr (!ROWS) {
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    feetx[l] = lane_bcast(v, 8 + l);
+                    feety[l] = lane_bcast(v, 12 + l);
+                }
+                com0x = lane_bcast(v, 16);
+                com0y = lane_bcast(v, 17);
+                swing_first = __builtin_amdgcn_readlane(sw, 18);
+            }
         }
     }
 
@@ -227,7 +256,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
         // computeSteps + buildPolygonMatrix: lane l builds the polygon of phase l
         if constexpr (!ROWS)
             for (int pbase = 0; pbase < sd.nphase; pbase += 64)
-                polygon_phase(sd, in, inst, wx[3], wy[3], pbase + lane, tab, cref);
+                polygon_phase(sd, feetx, feety, com0x, com0y, swing_first, wx[3], wy[3], pbase + lane, tab, cref);
         if (in.zref_phase)
             for (int i = lane; i < 2 * sd.nphase; i += 64) cref[i] = in.zref_phase[(size_t)inst * 2 * sd.nphase + i];
         if constexpr (!ROWS) {
@@ -243,10 +272,15 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 }
             }
         }
+        // (all loads first, from clamped -- always valid -- knots: conditional loads would be
+        // issued and waited for one chunk after the other)
 #pragma unroll
         for (int c = 0; c < NPL; c++) {
             ph[c] = sd.knot_phase[kc[c]];
             row0[c] = sd.knot_row0[kc[c]];
+        }
+#pragma unroll
+        for (int c = 0; c < NPL; c++) {
             if (kn[c] < N) {
                 const int E = ((ph[c] & 1) && ph[c] < 2 * sd.steps) ? 3 : 4;
                 validm |= ((1u << E) - 1u) << (4 * c);
@@ -267,6 +301,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
             }
         }
     }
+    STAMP(11);
     if (lane < QL + 4) W.wsKS[lane] = 0; // padding entries must name a valid knot
     for (int i = lane; i < QL * LDI; i += 64) W.Rinv[i] = 0.0;
     wsync();
@@ -359,6 +394,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
         else return e == 0 ? -lo[c] : hi[c];
     };
 
+    STAMP(15);
     // ---- unconstrained solution (x = -G^-1 g0, eiquadprog.hpp:188-191) ----
     double zxu[NPL], zyu[NPL];
 #pragma unroll

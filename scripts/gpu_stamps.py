@@ -4,7 +4,7 @@ os.environ["MPC_AMD_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mpc_amd import batches, planner as P
-names = ["prologue", "l1 rows", "s eval+psi", "select", "g gather", "d,r", "zn+t1", "add writes (+drop)", "zmp/margin out", "t2,t", "f,u,rho", "-", "scalars/active out", "jerk out", "com,vel out", "-"]
+names = ["prologue", "l1 rows", "s eval+psi", "select", "g gather", "d,r", "zn+t1", "add writes (+drop)", "zmp/margin out", "t2,t", "f,u,rho", "prologue: inputs+polygons", "scalars/active out", "jerk out", "com,vel out", "prologue: factor init"]
 def makespan(cost, slots):
     """Greedy list scheduling in the given order: what the hardware dispatcher does."""
     import heapq
@@ -36,7 +36,7 @@ def run(wl, B):
     q = np.percentile(tot, [50, 90, 99, 100])
     print("  cycles/solve percentiles 50/90/99/100: %.0f %.0f %.0f %.0f; iters max %d; simulated makespan on 2048 slots"
           " in dispatch order: %.0f cycles vs ideal %.0f" % (q[0], q[1], q[2], q[3], it.max(), makespan(tot, 2048), tot.sum() / 2048))
-    for i, n in enumerate(names[:15]):
+    for i, n in enumerate(names[:16]):
         print("  %-14s %9.0f cycles  %5.1f%%" % (n, d[:, i].mean(), 100 * d[:, i].sum() / tot.sum()))
 run("coupled", 8192)
 run("jerk", 8192)

@@ -29,4 +29,5 @@ pass f64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_IN
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass l2 TCC_HIT_sum TCC_MISS_sum
+pass icache SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_BUSY_CYCLES
 echo "all passes done"
