@@ -26,6 +26,17 @@ def test_library_exports_every_declared_symbol():
         assert getattr(lib, sym) is not None
 
 
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/mpc_amd.h must compile as C99 with no C++ or HIP in it."""
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "mpc_amd.h"\n'
+                   'int main(void) { mpcb_params p; mpcb_outputs o; mpcb_coupled_inputs i;\n'
+                   '  (void)p; (void)o; (void)i; (void)&mpcb_create; return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)],
+                   check=True)
+
+
 def test_create_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
