@@ -782,6 +782,9 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                         zz += z[i] * z[i];
                         zn += z[i] * np[i];
                     }
+                    // read ahead of the exchange below, whose barrier then lets thread 0 update it
+                    // without another one
+                    const double uq = u[iq];
                     block_argmin_sums(t1, kmin, zz, zn, red, redk, tid, flip);
                     const int l = t1 < DINF ? A[kmin] : 0;
                     DSTAMP(6);
@@ -793,11 +796,13 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                         done = true;
                         break;
                     }
-                    __syncthreads();
+                    // Every thread updates only entries of x and u that it alone touches in this
+                    // stretch, so the step needs no barrier of its own; the branches below start
+                    // with one where they go on to shared bookkeeping.
                     if (t2 >= DINF) { // dual step
                         for (int k = tid; k < iq; k += T) u[k] -= t * r[k];
                         if (tid == 0) {
-                            u[iq] += t;
+                            u[iq] = uq + t;
                             iai[l] = l;
                         }
                         __syncthreads();
@@ -805,19 +810,20 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                         continue;
                     }
                     for (int i = tid; i < n; i += T) x[i] += t * z[i];
-                    f += t * zn * (0.5 * t + u[iq]);
-                    __syncthreads();
+                    f += t * zn * (0.5 * t + uq);
                     for (int k = tid; k < iq; k += T) u[k] -= t * r[k];
-                    if (tid == 0) u[iq] += t;
-                    __syncthreads();
+                    if (tid == 0) u[iq] = uq + t;
                     if (t == t2) {
                         // add_constraint (eiquadprog.hpp:450-513)
                         falg += 6.0 * nn * (nn - iq - 1);
                         DSTAMP(10);
                         if constexpr (!LDSJ) {
+                            __syncthreads(); // rb shares the storage of z, which the step above read
                             add_coefs(tid, T, [] { __syncthreads(); });
                             __syncthreads();
                         }
+                        // new diagonal entry of R: the hypot chain ends in +-||d[iq..n-1]||
+                        const double dq = (n - 1 >= iq + 1 && suf[iq] != 0.0) ? (d[iq] < 0.0 ? -suf[iq] : suf[iq]) : d[iq];
                         DSTAMP(11);
                         for (int row = tid; row < n; row += T) {
                             if (n - 1 >= iq + 1) {
@@ -854,18 +860,14 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                             }
                         }
                         DSTAMP(14);
-                        __syncthreads();
-                        DSTAMP(15);
-                        if (tid == 0) {
-                            if (n - 1 >= iq + 1 && suf[iq] != 0.0) d[iq] = d[iq] < 0.0 ? -suf[iq] : suf[iq];
-                        }
-                        __syncthreads();
-                        for (int j = iq + 1 + tid; j < n; j += T) d[j] = 0.0;
-                        for (int i = tid; i <= iq; i += T) R[ridx(i, iq)] = d[i];
+                        // the new column of R is d1 with dq below it (d itself is not kept: the
+                        // next pass recomputes it).  No barrier: nothing here is read again before
+                        // the one that opens the next outer iteration.
+                        for (int i = tid; i <= iq; i += T) R[ridx(i, iq)] = i < iq ? d[i] : dq;
                         iq = ufirst(iq + 1);
-                        __syncthreads();
-                        const double dq = d[iq - 1];
+                        DSTAMP(15);
                         if (fabs(dq) <= EPS * R_norm) { // degenerate (:400-418)
+                            __syncthreads();
                             if (tid == 0) iaexcl[ip] = 0;
                             __syncthreads();
                             delete_constraint(ip);
