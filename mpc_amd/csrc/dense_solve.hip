@@ -680,13 +680,35 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     // is the longest chain of the pass; waves 1 and 2 share the rows of z; wave 3
                     // prepares the rotation coefficients of an addition, which is how two passes
                     // in three end and depends on d alone)
-                    if (!LDSJ || wave == 1 || wave == 2)
+                    // The LDS variant also folds the reductions of the step lengths into this
+                    // stretch: waves 1 and 2 leave their parts of z.z and z.n+, wave 0 the minimum
+                    // ratio u_k / r_k (from r still in registers), in the exchange buffer of this
+                    // pass; the barrier after the back substitution publishes all of it.
+                    double *xd = red + flip * RED_D;
+                    int *xk = redk + flip * RED_I;
+                    if constexpr (LDSJ) flip ^= 1;
+                    // (thread 0 rewrites u[iq] after the step: every thread reads it here, ahead of
+                    // the barrier that follows the back substitution)
+                    const double uq_early = u[iq];
+                    if (!LDSJ || wave == 1 || wave == 2) {
+                        double pz = 0.0, pn = 0.0;
                         for (int row = LDSJ ? tid - 64 : tid; row < n; row += LDSJ ? 128 : T) {
                             double acc = 0.0;
 #pragma unroll 8
                             for (int j = iq; j < n; j++) acc += J[(size_t)j * ldj + row] * d[j];
                             z[row] = acc;
+                            pz += acc * acc;
+                            pn += acc * np[row];
                         }
+                        if constexpr (LDSJ) {
+                            pz = wave_sum(pz);
+                            pn = wave_sum(pn);
+                            if (lane == 0) {
+                                xd[NW + wave] = pz;
+                                xd[2 * NW + wave] = pn;
+                            }
+                        }
+                    }
                     if constexpr (LDSJ) {
                         if (wave == 3) add_coefs(lane, 64, [] { wsync(); });
                     }
@@ -752,6 +774,19 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                             r1 *= iv1;
                             if (lane < iq) r[lane] = r0;
                             if (lane + 64 < iq) r[lane + 64] = r1;
+                            // step 2b: minimum of u_k / r_k over r_k > 0, lowest k on ties
+                            double ta = (lane < iq && r0 > 0.0) ? u[lane] / r0 : DINF;
+                            const double tb = (lane + 64 < iq && r1 > 0.0) ? u[lane + 64] / r1 : DINF;
+                            int ka = lane, aux = 0;
+                            if (tb < ta) {
+                                ta = tb;
+                                ka = lane + 64;
+                            }
+                            wave_argmin(ta, ka, aux);
+                            if (lane == 0) {
+                                xd[0] = ta;
+                                xk[0] = ka;
+                            }
                         }
                         __syncthreads();
                     } else {
@@ -767,25 +802,32 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                     }
                     DSTAMP(5);
                     // step lengths
-                    double t1 = DINF;
+                    double t1 = DINF, zz = 0.0, zn = 0.0, uq;
                     int kmin = 0x7fffffff;
-                    for (int k = tid; k < iq; k += T)
-                        if (r[k] > 0.0) {
-                            const double tmp = u[k] / r[k];
-                            if (tmp < t1 || (tmp == t1 && k < kmin)) {
-                                t1 = tmp;
-                                kmin = k;
+                    if constexpr (LDSJ) {
+                        t1 = xd[0];
+                        kmin = xk[0];
+                        zz = xd[NW + 1] + xd[NW + 2];
+                        zn = xd[2 * NW + 1] + xd[2 * NW + 2];
+                        uq = uq_early;
+                    } else {
+                        for (int k = tid; k < iq; k += T)
+                            if (r[k] > 0.0) {
+                                const double tmp = u[k] / r[k];
+                                if (tmp < t1 || (tmp == t1 && k < kmin)) {
+                                    t1 = tmp;
+                                    kmin = k;
+                                }
                             }
+                        for (int i = tid; i < n; i += T) {
+                            zz += z[i] * z[i];
+                            zn += z[i] * np[i];
                         }
-                    double zz = 0.0, zn = 0.0;
-                    for (int i = tid; i < n; i += T) {
-                        zz += z[i] * z[i];
-                        zn += z[i] * np[i];
+                        // read ahead of the exchange below, whose barrier then lets thread 0 update
+                        // it without another one
+                        uq = u[iq];
+                        block_argmin_sums(t1, kmin, zz, zn, red, redk, tid, flip);
                     }
-                    // read ahead of the exchange below, whose barrier then lets thread 0 update it
-                    // without another one
-                    const double uq = u[iq];
-                    block_argmin_sums(t1, kmin, zz, zn, red, redk, tid, flip);
                     const int l = t1 < DINF ? A[kmin] : 0;
                     DSTAMP(6);
                     const double t2 = fabs(zz) > EPS ? -s[ip] / zn : DINF;
