@@ -19,7 +19,10 @@
  *     synchronise.
  *   - Return value: 0 (or a non-negative count where stated) on success, a
  *     negative MPCB_E_* code on failure; mpcb_last_error() gives the message.
- *   - Thread compatibility: one handle may be used by one host thread at a time.
+ *   - Thread compatibility: one handle may be used by one host thread at a time, and by one
+ *     stream at a time: the hand-over list and the dense workspace belong to the handle, so
+ *     two `*_device` calls of one handle in flight on different streams would share them.
+ *     Distinct handles (also on one device) are independent.
  */
 #ifndef MPC_AMD_H_
 #define MPC_AMD_H_
@@ -153,6 +156,16 @@ int  mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_inpu
 int  mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in,
                         const mpcb_outputs *out);
 
+/* One batch over several GPUs from one host thread's point of view (HOST pointers): instance i
+ * is solved with handles[floor(i * n_handles / B)] -- contiguous shards, no exchange between
+ * devices, one internal host thread and one HIP stream per handle; returns when every shard is
+ * back.  The handles must have been created with the same shape and formulation, normally one
+ * per device ordinal (mpcb_params.device); two handles on the same ordinal also work.  The
+ * reference is single-threaded and has no counterpart; this is the multi-device form of
+ * mpcb_solve_coupled.  Returns the number of non-OK instances or a negative error. */
+int  mpcb_solve_coupled_multi(const mpcb_handle *handles, int32_t n_handles, int32_t B,
+                              const mpcb_coupled_inputs *in, const mpcb_outputs *out);
+
 /* State of B receding-horizon rollouts between two replans (device pointers, updated in
  * place): what the loop of tests/replanning/testPlannerXYconstraintMPC.cpp keeps in
  * actual_state_x/y, initial_feet_x/y and replanning_schedule. */
@@ -202,6 +215,10 @@ int  mpcb_solve_unconstrained(mpcb_handle h, int32_t B, const double *x0, const 
  * solve the first-stage kernel handed over to the dense second-stage kernel (working set
  * beyond its capacity, or a numerically singular reduced system).  Waits for the device. */
 int  mpcb_last_handover_count(mpcb_handle h);
+
+/* Diagnostic builds only (library compiled with -DMPCB_STAMPS): device buffer of 16 cycle
+ * counters per instance that the kernels fill; a no-op pointer store in the normal build. */
+int  mpcb_debug_set_stamp_buffer(mpcb_handle h, long long *dev);
 
 /* Copy an instance-independent matrix to the host (tests, diagnostics).
  * which: 0 = S (ZMP response, N x N), 1 = W^T (jerk response), 2 = CoM position

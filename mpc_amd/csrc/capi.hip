@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -41,8 +42,16 @@ struct mpcb_handle_s {
     mpcb::DevSetup ds;
     mpcb::DenseWs ws;
     int list_capacity = 0;   // entries ws.list can hold
-    int dense_blocks = 0;    // slots of ws.J / ws.R
-    std::vector<void *> dev_allocs;
+    int dense_slots = 0;     // slots of ws.J / ws.R (HBM-resident dense factors only)
+    int slot_target = 16;    // slots wanted: raised to the largest hand-over count seen (<= 512)
+    bool dense_in_lds = false; // the dense kernel keeps J and R in LDS: no HBM slots at all
+    std::vector<void *> dev_allocs;   // tables: freed by mpcb_destroy only
+    // hand-over count of the latest solve, copied to page-locked host memory behind the kernels;
+    // read (without waiting) at the start of the next solve to size the dense workspace
+    int *count_host = nullptr;
+    hipEvent_t count_event = nullptr;
+    bool count_pending = false;
+    hipStream_t own_stream = nullptr; // stream of the host-pointer entry points
     // device arena of the host-pointer entry points: grown when a batch needs more, kept
     // between calls (so they neither allocate nor free in steady state)
     void *stage_dev = nullptr;
@@ -84,6 +93,7 @@ struct Staging {
     static size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
     int commit() {
         if (need > h->stage_bytes) {
+            HIP_TRY(hipStreamSynchronize(h->own_stream));
             if (h->stage_dev) HIP_TRY(hipFree(h->stage_dev));
             h->stage_dev = nullptr;
             h->stage_bytes = 0;
@@ -107,7 +117,7 @@ struct Staging {
             return 0;
         }
         T *p = slice<T>(n);
-        HIP_TRY(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, h->own_stream));
         *dev = p;
         return 0;
     }
@@ -137,16 +147,18 @@ int stage_outputs(Staging &st, const mpcb_outputs &h, mpcb_outputs &d, size_t B,
     return 0;
 }
 
-int fetch_outputs(const mpcb_outputs &h, const mpcb_outputs &d, size_t B, size_t N) {
+// queues the copies back behind the kernels on `stream` and waits for all of them
+int fetch_outputs(const mpcb_outputs &h, const mpcb_outputs &d, size_t B, size_t N, hipStream_t stream) {
 #define BACK_(field, n)                                                                       \
     if (h.field)                                                                              \
-        HIP_TRY(hipMemcpy(h.field, d.field, (n) * sizeof(*h.field), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(h.field, d.field, (n) * sizeof(*h.field), hipMemcpyDeviceToHost, stream));
     BACK_(jerk_x, B * N) BACK_(jerk_y, B * N) BACK_(com_x, B * N) BACK_(com_y, B * N)
     BACK_(com_xd, B * N) BACK_(com_yd, B * N) BACK_(zmp_x, B * N) BACK_(zmp_y, B * N)
     BACK_(min_margin, B * N) BACK_(cost, B) BACK_(status, B) BACK_(iters, B) BACK_(n_active, B)
     BACK_(active_idx, B * (size_t)h.active_stride) BACK_(multipliers, B * (size_t)h.active_stride)
     BACK_(alg_flops, B) BACK_(slacks, B * 2 * N)
 #undef BACK_
+    HIP_TRY(hipStreamSynchronize(stream));
     return 0;
 }
 
@@ -232,52 +244,92 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
         h->dev_allocs.push_back(cnt);
         h->ws.count = cnt;
     }
+    if (params->formulation != MPCB_UNCONSTRAINED) {
+        // the dense kernel's LDS carve-up must fit a workgroup: found out here, not at the
+        // first solve
+        const size_t lds = mpcb::dense_lds_bytes_needed(ds, &h->dense_in_lds);
+        if (lds > 160 * 1024) {
+            mpcb_destroy(h);
+            return fail(MPCB_E_ARG, "horizon / number_of_steps too large for this formulation: the dense "
+                                    "second-stage kernel would need " + std::to_string(lds) +
+                                    " bytes of LDS per workgroup (limit 163840)");
+        }
+    }
+    if (hipHostMalloc((void **)&h->count_host, sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&h->count_event, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        mpcb_destroy(h);
+        return fail(MPCB_E_HIP, "creating the handle's stream, event or pinned counter failed");
+    }
+    *h->count_host = 0;
     *out = h;
     return 0;
 }
 
 namespace {
 
-// Grows the hand-over list and the dense kernel's HBM workspace to fit a batch of B.
-int ensure_workspace(mpcb_handle h, int B) {
-    if (B > h->list_capacity) {
-        int *lst = nullptr;
-        HIP_TRY(hipMalloc((void **)&lst, (size_t)B * sizeof(int)));
-        h->dev_allocs.push_back(lst);
-        h->ws.list = lst;
-        h->list_capacity = B;
+// Sizes the hand-over list for a batch of B and, when the dense kernel keeps its factors in
+// HBM, its J / R slots: a small number to begin with, raised to the largest hand-over count an
+// earlier solve of this handle reported (the kernel loops over the list with as many workgroups
+// as there are slots, so fewer slots than hand-overs is slower, never wrong).  Superseded
+// buffers are freed here, after the stream has drained.
+int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
+    if (h->count_pending && hipEventQuery(h->count_event) == hipSuccess) {
+        h->count_pending = false;
+        const int seen = *h->count_host;
+        if (seen > h->slot_target) h->slot_target = seen < 512 ? seen : 512;
     }
-    // one J and one R slot per resident workgroup; more flagged instances than slots
-    // are handled by the kernel's loop over the list
-    const int want = B < 512 ? B : 512;
-    if (want > h->dense_blocks) {
+    (void)hipGetLastError(); // hipEventQuery reports "not ready" through the error state
+    if (B > h->list_capacity) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (h->ws.list) HIP_TRY(hipFree(h->ws.list));
+        h->ws.list = nullptr;
+        h->list_capacity = 0;
+        int cap = 1024;
+        while (cap < B) cap *= 2;
+        HIP_TRY(hipMalloc((void **)&h->ws.list, (size_t)cap * sizeof(int)));
+        h->list_capacity = cap;
+    }
+    if (h->dense_in_lds) return 0;
+    int want = h->params.solver_mode == MPCB_MODE_DENSE ? 512 : h->slot_target;
+    if (want > B) want = B;
+    if (want > h->dense_slots) {
         const size_t n = (size_t)h->hs.nvar;
-        double *J = nullptr, *R = nullptr;
-        HIP_TRY(hipMalloc((void **)&J, (size_t)want * n * n * sizeof(double)));
-        h->dev_allocs.push_back(J);
-        HIP_TRY(hipMalloc((void **)&R, (size_t)want * n * n * sizeof(double)));
-        h->dev_allocs.push_back(R);
-        h->ws.J = J;
-        h->ws.R = R;
-        h->dense_blocks = want;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (h->ws.J) HIP_TRY(hipFree(h->ws.J));
+        if (h->ws.R) HIP_TRY(hipFree(h->ws.R));
+        h->ws.J = h->ws.R = nullptr;
+        h->dense_slots = 0;
+        HIP_TRY(hipMalloc((void **)&h->ws.J, (size_t)want * n * n * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&h->ws.R, (size_t)want * n * n * sizeof(double)));
+        h->dense_slots = want;
     }
     return 0;
 }
 
 // first stage (wave per QP), then the dense kernel over whatever it handed over
-int solve_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &out, int B, hipStream_t stream) {
-    if (B == 0) return 0;
-    int rc = ensure_workspace(h, B);
-    if (rc) return rc;
+int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &out, int B,
+                     const mpcb::DenseWs &ws, int dense_grid, hipStream_t stream) {
     // the slack formulation keeps about 2N rows active: beyond the first stage's capacity
     if (h->params.solver_mode == MPCB_MODE_DENSE || h->params.formulation == MPCB_BOX_SLACK) {
-        HIP_TRY(mpcb::launch_list_all(h->ws, B, stream));
+        HIP_TRY(mpcb::launch_list_all(ws, B, stream));
     } else {
-        HIP_TRY(hipMemsetAsync(h->ws.count, 0, sizeof(int), stream));
-        HIP_TRY(mpcb::launch_zspace(h->ds, di, out, B, h->ws, stream));
+        HIP_TRY(hipMemsetAsync(ws.count, 0, sizeof(int), stream));
+        HIP_TRY(mpcb::launch_zspace(h->ds, di, out, B, ws, stream));
     }
-    const int blocks = B < h->dense_blocks ? B : h->dense_blocks;
-    HIP_TRY(mpcb::launch_dense(h->ds, di, out, h->ws, blocks, stream));
+    HIP_TRY(mpcb::launch_dense(h->ds, di, out, ws, dense_grid, stream));
+    return 0;
+}
+
+int solve_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &out, int B, hipStream_t stream) {
+    if (B == 0) return 0;
+    int rc = ensure_workspace(h, B, stream);
+    if (rc) return rc;
+    const int cap = h->dense_in_lds ? 512 : h->dense_slots;
+    if ((rc = launch_two_stage(h, di, out, B, h->ws, B < cap ? B : cap, stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->count_host, h->ws.count, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(h->count_event, stream));
+    h->count_pending = true;
     return 0;
 }
 
@@ -287,8 +339,17 @@ void mpcb_destroy(mpcb_handle h) {
     if (!h) return;
     {
         DeviceGuard guard(h->params.device);
+        if (h->own_stream) {
+            (void)hipStreamSynchronize(h->own_stream);
+            (void)hipStreamDestroy(h->own_stream);
+        }
         for (void *p : h->dev_allocs) (void)hipFree(p);
+        if (h->ws.list) (void)hipFree(h->ws.list);
+        if (h->ws.J) (void)hipFree(h->ws.J);
+        if (h->ws.R) (void)hipFree(h->ws.R);
         if (h->stage_dev) (void)hipFree(h->stage_dev);
+        if (h->count_event) (void)hipEventDestroy(h->count_event);
+        if (h->count_host) (void)hipHostFree(h->count_host);
     }
     delete h;
 }
@@ -330,8 +391,9 @@ int mpcb_get_matrix(mpcb_handle h, int32_t which, double *dst) {
     return 0;
 }
 
-int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in,
-                              const mpcb_outputs *out, void *stream) {
+// argument checks shared by the coupled entry points; fills the kernels' input block
+static int coupled_arguments(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, const mpcb_outputs *out,
+                             mpcb::DevIn &di) {
     if (!h || !in || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
     const int form = h->params.formulation;
     if (form != MPCB_COUPLED_JERK && form != MPCB_COUPLED_VEL && form != MPCB_COUPLED_REF)
@@ -344,8 +406,6 @@ int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_input
         return fail(MPCB_E_ARG, "COUPLED_REF with rows_pqr needs zref_phase");
     if ((out->active_idx || out->multipliers) && out->active_stride <= 0)
         return fail(MPCB_E_ARG, "active_stride must be positive");
-    DeviceGuard guard(h->params.device);
-    mpcb::DevIn di;
     std::memset(&di, 0, sizeof(di));
     di.x0 = in->x0;
     di.y0 = in->y0;
@@ -356,7 +416,63 @@ int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_input
     di.com0 = in->com0;
     di.rows_pqr = in->rows_pqr;
     di.zref_phase = in->zref_phase;
+    return 0;
+}
+
+int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in,
+                              const mpcb_outputs *out, void *stream) {
+    mpcb::DevIn di;
+    int rc = coupled_arguments(h, B, in, out, di);
+    if (rc || B == 0) return rc;
+    DeviceGuard guard(h->params.device);
     return solve_two_stage(h, di, *out, B, (hipStream_t)stream);
+}
+
+int mpcb_solve_coupled_multi(const mpcb_handle *handles, int32_t n_handles, int32_t B,
+                             const mpcb_coupled_inputs *in, const mpcb_outputs *out) {
+    if (!handles || n_handles <= 0 || !in || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative size");
+    for (int g = 0; g < n_handles; g++) {
+        if (!handles[g]) return fail(MPCB_E_ARG, "null handle in the list");
+        for (int g2 = 0; g2 < g; g2++)
+            if (handles[g2] == handles[g]) return fail(MPCB_E_ARG, "the same handle is listed twice");
+        if (handles[g]->hs.N != handles[0]->hs.N || handles[g]->hs.m != handles[0]->hs.m ||
+            handles[g]->hs.nphase != handles[0]->hs.nphase ||
+            handles[g]->params.formulation != handles[0]->params.formulation)
+            return fail(MPCB_E_ARG, "the handles were created with different shapes");
+    }
+    const size_t N = (size_t)handles[0]->hs.N, m = (size_t)handles[0]->hs.m, P = (size_t)handles[0]->hs.nphase;
+    const size_t as = out->active_stride > 0 ? (size_t)out->active_stride : 0;
+    std::vector<int> rcs(n_handles, 0);
+    std::vector<std::string> msgs(n_handles);
+    auto work = [&](int g) {
+        // contiguous shard: instance i goes to handle floor(i * n_handles / B)
+        const size_t first = ((size_t)g * (size_t)B + n_handles - 1) / n_handles;
+        const size_t last = ((size_t)(g + 1) * (size_t)B + n_handles - 1) / n_handles;
+        if (last <= first) return;
+        mpcb_coupled_inputs si = *in;
+        mpcb_outputs so = *out;
+#define IN_(field, w) if (si.field) si.field += first * (w);
+        IN_(x0, 3) IN_(y0, 3) IN_(speed, 2) IN_(feet_x, 4) IN_(feet_y, 4) IN_(swing0, 1) IN_(com0, 2)
+        IN_(rows_pqr, m * 3) IN_(zref_phase, P * 2)
+#undef IN_
+#define OUT_(field, w) if (so.field) so.field += first * (w);
+        OUT_(jerk_x, N) OUT_(jerk_y, N) OUT_(com_x, N) OUT_(com_y, N) OUT_(com_xd, N) OUT_(com_yd, N)
+        OUT_(zmp_x, N) OUT_(zmp_y, N) OUT_(min_margin, N) OUT_(cost, 1) OUT_(status, 1) OUT_(iters, 1)
+        OUT_(n_active, 1) OUT_(active_idx, as) OUT_(multipliers, as) OUT_(alg_flops, 1) OUT_(slacks, 2 * N)
+#undef OUT_
+        rcs[g] = mpcb_solve_coupled(handles[g], (int32_t)(last - first), &si, &so);
+        if (rcs[g] < 0) msgs[g] = mpcb_last_error(); // the message is per thread: carry it over
+    };
+    std::vector<std::thread> threads;
+    for (int g = 1; g < n_handles; g++) threads.emplace_back(work, g);
+    work(0);
+    for (auto &t : threads) t.join();
+    int bad = 0;
+    for (int g = 0; g < n_handles; g++) {
+        if (rcs[g] < 0) return fail(rcs[g], "device " + std::to_string(handles[g]->params.device) + ": " + msgs[g]);
+        bad += rcs[g];
+    }
+    return bad;
 }
 
 int mpcb_replan_sweep_device(mpcb_handle h, int32_t B, int32_t n_stages, int32_t use_com_correction,
@@ -466,9 +582,8 @@ int mpcb_solve_unconstrained(mpcb_handle h, int32_t B, const double *x0, const d
         return stage_outputs(st, *out, dout, b, N);
     };
     if ((rc = stage()) || (rc = st.commit()) || (rc = stage())) return rc;
-    if ((rc = mpcb_solve_unconstrained_device(h, B, dx0, dz, &dout, nullptr))) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    if ((rc = fetch_outputs(*out, dout, b, N))) return rc;
+    if ((rc = mpcb_solve_unconstrained_device(h, B, dx0, dz, &dout, h->own_stream))) return rc;
+    if ((rc = fetch_outputs(*out, dout, b, N, h->own_stream))) return rc;
     return 0;
 }
 
@@ -492,9 +607,8 @@ int mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, 
         return stage_outputs(st, *out, dout, b, N);
     };
     if ((rc = stage()) || (rc = st.commit()) || (rc = stage())) return rc;
-    if ((rc = mpcb_solve_coupled_device(h, B, &di, &dout, nullptr))) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    if ((rc = fetch_outputs(*out, dout, b, N))) return rc;
+    if ((rc = mpcb_solve_coupled_device(h, B, &di, &dout, h->own_stream))) return rc;
+    if ((rc = fetch_outputs(*out, dout, b, N, h->own_stream))) return rc;
     return count_not_ok(out->status, B);
 }
 
@@ -513,9 +627,8 @@ int mpcb_solve_box(mpcb_handle h, int32_t B, const double *x0, const double *zmi
         return stage_outputs(st, *out, dout, b, N);
     };
     if ((rc = stage()) || (rc = st.commit()) || (rc = stage())) return rc;
-    if ((rc = mpcb_solve_box_device(h, B, dx0, dmin, dmax, &dout, nullptr))) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    if ((rc = fetch_outputs(*out, dout, b, N))) return rc;
+    if ((rc = mpcb_solve_box_device(h, B, dx0, dmin, dmax, &dout, h->own_stream))) return rc;
+    if ((rc = fetch_outputs(*out, dout, b, N, h->own_stream))) return rc;
     return count_not_ok(out->status, B);
 }
 

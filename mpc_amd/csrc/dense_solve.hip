@@ -1044,6 +1044,13 @@ size_t dense_lds_bytes(const DevSetup &sd, bool ldsj) {
 
 } // namespace
 
+size_t dense_lds_bytes_needed(const DevSetup &sd, bool *in_lds) {
+    // 160 KB of LDS per workgroup at most; keep a margin for the static part
+    const bool ldsj = dense_lds_bytes(sd, true) <= 160 * 1024 - 256;
+    if (in_lds) *in_lds = ldsj;
+    return dense_lds_bytes(sd, ldsj) + 256;
+}
+
 hipError_t launch_list_all(const DenseWs &ws, int B, hipStream_t stream) {
     hipLaunchKernelGGL(list_all_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, ws.list, ws.count, B);
     return hipGetLastError();

@@ -66,6 +66,10 @@ hipError_t launch_list_all(const DenseWs &ws, int B, hipStream_t stream);
 hipError_t launch_dense(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, const DenseWs &ws,
                         int blocks, hipStream_t stream);
 
+// LDS bytes one workgroup of the dense kernel needs for this shape (dynamic + static part);
+// *in_lds: whether it keeps J and R in LDS, in which case ws.J / ws.R are never touched.
+size_t dense_lds_bytes_needed(const DevSetup &sd, bool *in_lds);
+
 // MPCPlanner::solveQP for B instances (handle built with MPCB_UNCONSTRAINED).
 hipError_t launch_unconstrained(const DevSetup &sd, const double *x0, const double *zref,
                                 const mpcb_outputs &out, int B, hipStream_t stream);

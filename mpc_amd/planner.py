@@ -23,7 +23,8 @@ MODE_AUTO, MODE_DENSE = 0, 1
 EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constraints", "mpcb_num_phases",
            "mpcb_solve_coupled_device", "mpcb_solve_coupled", "mpcb_solve_box_device",
            "mpcb_solve_box", "mpcb_get_matrix", "mpcb_replan_sweep_device",
-           "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained", "mpcb_last_handover_count")
+           "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained", "mpcb_last_handover_count",
+           "mpcb_solve_coupled_multi", "mpcb_debug_set_stamp_buffer")
 
 
 class Params(C.Structure):
@@ -76,6 +77,8 @@ def load_library():
                                                   C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_solve_coupled.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CoupledInputs),
                                            C.POINTER(Outputs)]
+        lib.mpcb_solve_coupled_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
+                                                 C.POINTER(CoupledInputs), C.POINTER(Outputs)]
         lib.mpcb_solve_box_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_get_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -289,6 +292,35 @@ class BatchedPlanner:
                 raise ValueError("output array %s does not fit the batch" % name)
             setattr(o, name, a.ctypes.data)
         _check(load_library().mpcb_solve_coupled(self._h, B, C.byref(ci), C.byref(o)))
+        return res
+
+    @staticmethod
+    def solve_coupled_multi(planners, x0, y0, speed, feet_x, feet_y, swing0, com0=None,
+                            outputs=DEFAULT_OUTPUTS, out=None):
+        """One batch over several planners (normally one per GPU) through
+        mpcb_solve_coupled_multi: numpy in, numpy out, contiguous shards, one host thread and
+        one stream per planner inside the library."""
+        first = planners[0]
+        f64 = np.float64
+        arrs = dict(x0=np.ascontiguousarray(x0, f64), y0=np.ascontiguousarray(y0, f64),
+                    speed=np.ascontiguousarray(speed, f64), feet_x=np.ascontiguousarray(feet_x, f64),
+                    feet_y=np.ascontiguousarray(feet_y, f64),
+                    swing0=np.ascontiguousarray(swing0, np.int32),
+                    com0=None if com0 is None else np.ascontiguousarray(com0, f64))
+        B = arrs["x0"].shape[0]
+        ci = CoupledInputs()
+        for k, a in arrs.items():
+            if a is not None:
+                setattr(ci, k, a.ctypes.data)
+        res = out if out is not None else first.host_output_arrays(B, outputs)
+        o = Outputs()
+        o.active_stride = first.active_stride
+        for name, a in res.items():
+            if a.shape[0] != B or not a.flags.c_contiguous:
+                raise ValueError("output array %s does not fit the batch" % name)
+            setattr(o, name, a.ctypes.data)
+        hs = (C.c_void_p * len(planners))(*[pl._h for pl in planners])
+        _check(load_library().mpcb_solve_coupled_multi(hs, len(planners), B, C.byref(ci), C.byref(o)))
         return res
 
     def prepare_box(self, x0, zmin, zmax):

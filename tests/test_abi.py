@@ -61,7 +61,7 @@ def test_splitmix_streams_are_slice_invariant():
     for k in full:
         assert np.array_equal(full[k][32:48], part[k]), k
     d = batches.decoupled_batch(8, first=3)
-    assert (d["xmax"] >= d["xmin"]).all() or True
+    assert (d["xmax"] > d["xmin"]).all() and (d["ymax"] > d["ymin"]).all()
     assert d["xmin"].shape == (8, 100)
     s = batches.SplitMix(np.arange(4), seed=1)
     u = s.uniform()
