@@ -156,6 +156,21 @@ int  mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_inpu
 int  mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in,
                         const mpcb_outputs *out);
 
+/* The same as mpcb_solve_coupled_device for callers that cannot allocate device memory --
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No
+ * counterpart in the reference.  mpcb_solve_coupled_device sizes its hand-over list and the
+ * dense second stage's J / R slots with hipMalloc on first use and when a batch outgrows them;
+ * this entry point keeps them in a static device array instead (19.8 MiB per GPU, held from
+ * the moment the library is loaded on that GPU until the process ends) and calls no hipMalloc,
+ * hipFree or other allocating routine.  Limits, rejected with MPCB_E_ARG: B <= 65536 and at
+ * most 400 variables per QP (horizon <= 200); the dense stage has 8 slots, so a batch that
+ * hands many instances over runs that stage 8 at a time.  Every call on a GPU -- from any
+ * handle, stream or thread -- uses that GPU's one array: calls that overlap on one GPU race;
+ * serialise them (one stream, or events).  Results are bit-identical to
+ * mpcb_solve_coupled_device.  mpcb_last_handover_count does not see these calls. */
+int  mpcb_solve_coupled_device_noalloc(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in,
+                                       const mpcb_outputs *out, void *stream);
+
 /* One batch over several GPUs from one host thread's point of view (HOST pointers): instance i
  * is solved with handles[floor(i * n_handles / B)] -- contiguous shards, no exchange between
  * devices, one internal host thread and one HIP stream per handle; returns when every shard is

@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -35,6 +36,25 @@ template <class T> int upload(const std::vector<T> &h, T **d) {
 }
 
 } // namespace
+
+// Scratch of mpcb_solve_coupled_device_noalloc: the hand-over counter and list of the first
+// stage and the dense second stage's J / R slots, in device memory that exists from the moment
+// the library is loaded on a GPU until the process ends -- the entry point therefore never
+// allocates.  Every GPU holds its own copy at its own address; g_scratch[device] is that
+// address (hipGetSymbolAddress, taken once per device in mpcb_create with the device current).
+// Host code must use that pointer, never the array's name.
+constexpr int NOALLOC_MAX_BATCH = 65536;   // instances per call
+constexpr int NOALLOC_MAX_NVAR = 400;      // variables of one QP (horizon 200, both axes)
+constexpr int NOALLOC_SLOTS = 8;           // J / R slots of the dense stage
+constexpr size_t SCRATCH_LIST_OFF = 256;
+constexpr size_t SCRATCH_J_OFF = SCRATCH_LIST_OFF + (size_t)NOALLOC_MAX_BATCH * sizeof(int);
+constexpr size_t SCRATCH_SLOT_BYTES = (size_t)NOALLOC_MAX_NVAR * NOALLOC_MAX_NVAR * sizeof(double);
+constexpr size_t SCRATCH_R_OFF = SCRATCH_J_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BYTES;
+constexpr size_t SCRATCH_BYTES = SCRATCH_R_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BYTES; // 19.8 MiB
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+constexpr int MAX_DEVICES = 64;
+static unsigned char *g_scratch[MAX_DEVICES] = {nullptr};
+static std::mutex g_scratch_mutex;
 
 struct mpcb_handle_s {
     mpcb_params params;
@@ -194,6 +214,19 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
     if (!guard.ok) {
         delete h;
         return fail(MPCB_E_HIP, "hipSetDevice failed");
+    }
+    if (params->device < MAX_DEVICES) {
+        // address of this device's copy of the scratch array (see its declaration)
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch[params->device]) {
+            unsigned char *ptr = nullptr;
+            hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !ptr) {
+                delete h;
+                return fail(MPCB_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+            }
+            g_scratch[params->device] = ptr;
+        }
     }
     const mpcb::HostSetup &hs = h->hs;
     mpcb::DevSetup &ds = h->ds;
@@ -426,6 +459,31 @@ int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_input
     if (rc || B == 0) return rc;
     DeviceGuard guard(h->params.device);
     return solve_two_stage(h, di, *out, B, (hipStream_t)stream);
+}
+
+int mpcb_solve_coupled_device_noalloc(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in,
+                                      const mpcb_outputs *out, void *stream) {
+    mpcb::DevIn di;
+    int rc = coupled_arguments(h, B, in, out, di);
+    if (rc || B == 0) return rc;
+    if (B > NOALLOC_MAX_BATCH)
+        return fail(MPCB_E_ARG, "mpcb_solve_coupled_device_noalloc: at most " + std::to_string(NOALLOC_MAX_BATCH) +
+                                    " instances per call");
+    if (h->hs.nvar > NOALLOC_MAX_NVAR)
+        return fail(MPCB_E_ARG, "mpcb_solve_coupled_device_noalloc: at most " + std::to_string(NOALLOC_MAX_NVAR) +
+                                    " variables per QP (horizon 200)");
+    if (h->params.device >= MAX_DEVICES || !g_scratch[h->params.device])
+        return fail(MPCB_E_ARG, "mpcb_solve_coupled_device_noalloc: no scratch on this device");
+    DeviceGuard guard(h->params.device);
+    // the handle's tables with this device's static scratch in place of the allocated workspace
+    unsigned char *ptr = g_scratch[h->params.device];
+    mpcb::DenseWs ws = h->ws;
+    ws.count = reinterpret_cast<int *>(ptr);
+    ws.list = reinterpret_cast<int *>(ptr + SCRATCH_LIST_OFF);
+    ws.J = reinterpret_cast<double *>(ptr + SCRATCH_J_OFF);
+    ws.R = reinterpret_cast<double *>(ptr + SCRATCH_R_OFF);
+    const int cap = h->dense_in_lds ? 512 : NOALLOC_SLOTS;
+    return launch_two_stage(h, di, *out, B, ws, B < cap ? B : cap, (hipStream_t)stream);
 }
 
 int mpcb_solve_coupled_multi(const mpcb_handle *handles, int32_t n_handles, int32_t B,

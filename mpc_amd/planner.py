@@ -24,7 +24,7 @@ EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constrain
            "mpcb_solve_coupled_device", "mpcb_solve_coupled", "mpcb_solve_box_device",
            "mpcb_solve_box", "mpcb_get_matrix", "mpcb_replan_sweep_device",
            "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained", "mpcb_last_handover_count",
-           "mpcb_solve_coupled_multi", "mpcb_debug_set_stamp_buffer")
+           "mpcb_solve_coupled_device_noalloc", "mpcb_solve_coupled_multi", "mpcb_debug_set_stamp_buffer")
 
 
 class Params(C.Structure):
@@ -77,6 +77,7 @@ def load_library():
                                                   C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_solve_coupled.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CoupledInputs),
                                            C.POINTER(Outputs)]
+        lib.mpcb_solve_coupled_device_noalloc.argtypes = lib.mpcb_solve_coupled_device.argtypes
         lib.mpcb_solve_coupled_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                                                  C.POINTER(CoupledInputs), C.POINTER(Outputs)]
         lib.mpcb_solve_box_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
@@ -229,13 +230,17 @@ class BatchedPlanner:
             setattr(ci, k, t.data_ptr())
         return B, ci, ts
 
-    def solve_coupled_prepared(self, prepared, outputs=DEFAULT_OUTPUTS, out=None, stream=None):
+    def solve_coupled_prepared(self, prepared, outputs=DEFAULT_OUTPUTS, out=None, stream=None,
+                               no_alloc=False):
+        """no_alloc=True goes through mpcb_solve_coupled_device_noalloc (static scratch instead of
+        the handle's allocated workspace; pass `out` so that nothing is allocated here either)."""
         B, ci, _ = prepared
         if out is None:
             out = self._alloc_outputs(B, outputs)
         res, o = out
-        _check(load_library().mpcb_solve_coupled_device(self._h, B, C.byref(ci), C.byref(o),
-                                                        self._stream(stream)))
+        lib = load_library()
+        fn = lib.mpcb_solve_coupled_device_noalloc if no_alloc else lib.mpcb_solve_coupled_device
+        _check(fn(self._h, B, C.byref(ci), C.byref(o), self._stream(stream)))
         return res
 
     def solve_coupled(self, x0, y0, speed, feet_x=None, feet_y=None, swing0=None, com0=None,

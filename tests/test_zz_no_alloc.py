@@ -1,0 +1,71 @@
+"""The entry point that allocates nothing (static device scratch instead of the handle's
+hipMalloc'd hand-over list and dense workspace) returns, bit for bit, what
+mpcb_solve_coupled_device returns -- on two calls in a row, the second with a smaller batch,
+with instances going through the dense second stage (the scratch's J / R slots) in both."""
+import numpy as np
+import pytest
+
+from mpc_amd import batches
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from mpc_amd import planner
+    planner.load_library()
+    return planner
+
+
+def _compare(P, pl, B, first, expect_handover):
+    import torch
+    bt = batches.coupled_batch(B, first=first)
+    prepared = pl.prepare_coupled(**bt)
+    ref = {k: v.cpu().numpy() for k, v in pl.solve_coupled_prepared(prepared).items()}
+    handed = pl.last_handover_count()
+    out = pl._alloc_outputs(B, P.ALL_OUTPUTS)
+    for t in out[0].values():  # whatever the call does not write must show up
+        t.fill_(-7)
+    torch.cuda.synchronize()
+    got = pl.solve_coupled_prepared(prepared, out=out, no_alloc=True)
+    torch.cuda.synchronize()
+    for k, v in ref.items():
+        assert np.array_equal(got[k].cpu().numpy(), v, equal_nan=True), (B, k)
+    assert (handed > 0) == expect_handover
+    return handed
+
+
+def test_no_alloc_entry_point_matches_allocating_one(P):
+    N, steps = 200, 20
+    # weight_R = 1e-6: working sets beyond the first stage's capacity, so part of each batch is
+    # handed to the dense stage, whose J / R slots are the scratch's (8 of them: the first batch
+    # hands over more instances than that)
+    hard = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=1e-6, weight_Q=1.0, number_of_steps=steps)
+    h1 = _compare(P, hard, 40, 0, True)
+    h2 = _compare(P, hard, 12, 500, True)
+    assert h1 > 8 and h2 >= 1
+    # the benchmark's weights: nothing is handed over, counter and list only
+    easy = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
+    _compare(P, easy, 96, 0, False)
+    _compare(P, easy, 33, 96, False)
+    _compare(P, hard, 20, 900, True)  # and the first handle again, after another one used the scratch
+
+
+def test_no_alloc_entry_point_rejects_sizes_beyond_its_scratch(P):
+    big = P.BatchedPlanner(300, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=15)
+    bt = batches.coupled_batch(4)
+    prepared = big.prepare_coupled(**bt)
+    with pytest.raises(P.MpcError, match="400 variables"):
+        big.solve_coupled_prepared(prepared, no_alloc=True)
+    pl = P.BatchedPlanner(200, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=20)
+    B = 65537
+    bt = batches.coupled_batch(B)
+    prepared = pl.prepare_coupled(**bt)
+    out = pl._alloc_outputs(B, ("status",))
+    with pytest.raises(P.MpcError, match="65536"):
+        pl.solve_coupled_prepared(prepared, out=out, no_alloc=True)
+    box = P.BatchedPlanner(100, formulation=P.BOX_1D, weight_R=1.0)
+    with pytest.raises(P.MpcError, match="coupled"):
+        box.solve_coupled_prepared(pl.prepare_coupled(**batches.coupled_batch(2)), no_alloc=True)
