@@ -1,0 +1,800 @@
+// Dense dual active-set kernel for SMALL box problems (n = N <= ~104 variables): one QP per
+// workgroup, every matrix in LDS, built for the latency of one pass rather than throughput.
+//
+// Second stage behind the wave-per-QP kernel for MPCB_BOX_1D: the instances that kernel cannot
+// certify (working sets beyond its capacity, numerically singular reduced systems -- in
+// practice the numerically infeasible draws, whose working set grows to n over ~200 outer
+// iterations) are solved here with the reference's method (eiquadprog.hpp:130-592): the full
+// J = L^-T Q and a triangular factor of the working set, same pivot rules, tolerances and step
+// formulas.  What differs from a transliteration is how the two factors are updated:
+//
+//  * add_constraint (eiquadprog.hpp:450-513) rotates the pairs (j-1, j), j = n-1 .. iq+1, so
+//    that d2 = J2' n+ collapses into its first entry.  With the suffix sums
+//    P_j = sum_{i>=j} J[:,i] d_i and nu_j = ||d[j..]|| the result of that whole sequence is
+//        new J[:,iq] = P_iq / nu_iq                      ( = z / ||d2|| )
+//        new J[:,j]  = (nu_j/nu_{j-1}) J[:,j-1] - d_{j-1}/(nu_{j-1} nu_j) P_j ,  j > iq
+//    (up to the signs of columns, which cancel in every product the method forms).  P_iq is
+//    the step direction z itself, so the pass that computes z in four column segments (one
+//    per wave) leaves exactly the partial sums the update needs: the update is a second sweep
+//    of independent fused multiply-adds, four waves on four column segments, with no
+//    sequential rotation chain.
+//  * Instead of R the kernel keeps T = R^-1 (packed upper triangle).  r = R^-1 d1 is then a
+//    product, split over the four waves, instead of a back substitution chain of length iq;
+//    an added constraint appends the column [-r; 1] / nu_iq; a dropped constraint qq needs
+//    the plane rotations that move row qq of T (entries qq .. iq-1 =: g) into its last entry,
+//    applied to the columns of T and of J (delete_constraint, eiquadprog.hpp:516-592, does
+//    the same to R's rows and J's columns).  With prefix sums Q_j = sum_{i<=j} g_i col_i and
+//    rho_j = ||g[qq..j]|| that sequence is again closed-form:
+//        new col_j = g_{j+1}/(rho_{j+1} rho_j) Q_j - (rho_j/rho_{j+1}) col_{j+1}
+//    and the freed direction is Q_{iq-1} / rho_{iq-1}.
+//
+// All four waves evaluate the scalar decisions (most violated row, step lengths, blocking
+// constraint) redundantly from the same LDS partial sums, so every wave holds x, u, the
+// working set and the decisions in registers and the workgroup meets at three barriers per
+// outer iteration (one more per dropped constraint) -- the previous arrangement needed a
+// barrier per reduction and serialised on one wave's back substitution.
+#include <hip/hip_runtime.h>
+
+#include "device_common.h"
+#include "kernels.h"
+
+namespace mpcb {
+namespace {
+
+// Diagnostic build only (-DMPCB_STAMPS): cycles per section into sd.dbg[inst*16 + section].
+#ifdef MPCB_STAMPS
+#define BSTAMP(i)                                          \
+    do {                                                   \
+        const long long t_ = __builtin_amdgcn_s_memtime(); \
+        stamp_acc[i] += t_ - stamp_t;                      \
+        stamp_t = t_;                                      \
+    } while (0)
+#else
+#define BSTAMP(i) \
+    do {          \
+    } while (0)
+#endif
+
+constexpr int BT = 256, BW = 4, HALF = 64, PSTR = 128; // threads, waves, lanes, stride of the partial-sum arrays
+
+__device__ __forceinline__ double bcast(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                            __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+// value of lane 63 - l (lane reversal through the LDS crossbar)
+__device__ __forceinline__ double lane_reverse(double v, int lane) {
+    const int src = (63 - lane) << 2;
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(v)),
+                            __builtin_amdgcn_ds_bpermute(src, __double2loint(v)));
+}
+
+__device__ __forceinline__ double shift_down(double a0, int lane) { // value of lane + 1
+    return dpp_f64<0x130, 0xF>(0.0, a0);
+}
+__device__ __forceinline__ int shift_down(int a0, int lane) { return dpp_i32<0x130, 0xF>(0, a0); }
+
+__global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mpcb_outputs out, DenseWs ws) {
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = ufirst(tid >> 6);
+    const int N = sd.N, n = N, m = 2 * N, ldj = n | 1;
+    // ---- LDS -------------------------------------------------------------------
+    double *J = smem;                                 // n x ldj, column-major
+    double *Tp = J + (size_t)n * ldj;                 // T = R^-1, packed: T(i,k) at k(k+1)/2 + i, i <= k
+    double *xs = Tp + (size_t)n * (n + 1) / 2 + PSTR; // x by index (identical copies written by every wave)
+    double *dsv = xs + PSTR;                          // d by index
+    double *nus = dsv + PSTR;                         // suffix norms of d / prefix norms of g
+    double *ca = nus + PSTR + 1, *cb = ca + PSTR;     // update coefficients per column
+    double *gs = cb + PSTR;                           // row qq of T
+    double *ins = gs + PSTR;                          // reciprocals of nus
+    double *zc = ins + PSTR;                          // Toeplitz column of Zu
+    double *dpart = zc + PSTR;                        // [BW][PSTR] partial sums of d = J' n+
+    double *zpart = dpart + BW * PSTR;                // [BW][PSTR] partial sums of z = J2 d2
+    double *rpart = zpart + BW * PSTR;                // [BW][PSTR] partial sums of r = T d1
+    double *mpart = rpart + BW * PSTR;                // [BW][PSTR] partial sums of the ZMP
+
+    // a lane owns the indices i0 = lane and i1 = lane + 64 of every length-n object
+    const int i0 = lane, i1 = lane + HALF;
+    const bool v0 = i0 < n, v1 = i1 < n;
+    const int c0 = v0 ? i0 : n - 1, c1 = v1 ? i1 : n - 1;
+
+    for (int k = tid; k < N; k += BT) zc[k] = ws.zu_col[k];
+    const int count = *ws.count;
+    for (int entry = blockIdx.x; entry < count; entry += gridDim.x) {
+        const int inst = ws.list[entry];
+#ifdef MPCB_STAMPS
+        long long stamp_acc[16] = {0};
+        long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
+        __syncthreads();
+        // ---- inputs --------------------------------------------------------------
+        double w4[4];
+        {
+            const double *px = in.x0 + (size_t)inst * 3;
+            w4[0] = px[0];
+            w4[1] = px[1];
+            w4[2] = px[2];
+            w4[3] = 0.0;
+        }
+        const double lo0 = v0 ? in.zmin[(size_t)inst * N + i0] : -DINF, hi0 = v0 ? in.zmax[(size_t)inst * N + i0] : DINF;
+        const double lo1 = v1 ? in.zmin[(size_t)inst * N + i1] : -DINF, hi1 = v1 ? in.zmax[(size_t)inst * N + i1] : DINF;
+        double zf0, zf1; // Zx x0 at the lane's knots
+        {
+            const double *a = ws.zx + (size_t)c0 * 3, *b = ws.zx + (size_t)c1 * 3;
+            zf0 = a[0] * w4[0] + a[1] * w4[1] + a[2] * w4[2];
+            zf1 = b[0] * w4[0] + b[1] * w4[1] + b[2] * w4[2];
+        }
+        // J = L^-T (eiquadprog.hpp:174-176), x = -G^-1 g0, f = 1/2 g0'x (:188-191)
+        for (int idx = tid; idx < n * n; idx += BT) {
+            const int col = idx / n, row = idx - col * n;
+            J[(size_t)col * ldj + row] = ws.J1[(size_t)col * N + row];
+        }
+        double x0r, x1r;
+        {
+            const double *a = sd.Kx + (size_t)c0 * 4, *b = sd.Kx + (size_t)c1 * 4;
+            x0r = a[0] * w4[0] + a[1] * w4[1] + a[2] * w4[2];
+            x1r = b[0] * w4[0] + b[1] * w4[1] + b[2] * w4[2];
+        }
+        double f = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) f += sd.F[a * 4 + b] * w4[a] * w4[b];
+        if (v0) xs[i0] = x0r;
+        if (v1) xs[i1] = x1r;
+
+        double u0 = 0.0, u1 = 0.0, uo0 = 0.0, uo1 = 0.0, xo0 = 0.0, xo1 = 0.0;
+        int A0 = 0, A1 = 0, Ao0 = 0, Ao1 = 0;
+        // bit 0 / 1: lower / upper bound row of knot i0, bit 2 / 3: of knot i1
+        unsigned actm = 0, exclm = 0xf;
+        const unsigned validm = (v0 ? 3u : 0u) | (v1 ? 12u : 0u);
+        int iq = 0, iters = 0, passes = 0, status = MPCB_OK;
+        double R_norm = 1.0;
+        const double nn = (double)n, mm = (double)m;
+        double falg = 2.0 * nn * nn;
+        double zm0 = 0.0, zm1 = 0.0; // ZMP at the lane's knots
+        bool zmp_current = false;
+
+        // ZMP at the current x: zfree + Zu x, the triangular product cut into four bands of
+        // columns (one per wave); ends with every wave holding the sums.  One barrier.
+        auto eval_zmp = [&]() {
+            const int band = (N + BW - 1) / BW, j0 = wave * band;
+            double a0 = wave == 0 ? zf0 : 0.0, a1 = wave == 0 ? zf1 : 0.0;
+            const int jend = min(j0 + band, N);
+            // eight columns' loads are issued together (clamped, the tail masked): with one wave
+            // per SIMD nothing else hides the LDS latency
+            for (int jb = j0; jb < jend; jb += 8) {
+                double xv[8], t0v[8], t1v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int j = min(jb + e, jend - 1);
+                    xv[e] = xs[j];
+                    t0v[e] = zc[max(c0 - j, 0)];
+                    t1v[e] = zc[max(c1 - j, 0)];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int j = jb + e;
+                    const bool in = j < jend;
+                    a0 = fma((in && j <= i0) ? t0v[e] : 0.0, xv[e], a0);
+                    a1 = fma((in && j <= i1) ? t1v[e] : 0.0, xv[e], a1);
+                }
+            }
+            mpart[wave * PSTR + i0] = a0;
+            mpart[wave * PSTR + i1] = a1;
+            __syncthreads();
+            zm0 = ((mpart[i0] + mpart[PSTR + i0]) + mpart[2 * PSTR + i0]) + mpart[3 * PSTR + i0];
+            zm1 = ((mpart[i1] + mpart[PSTR + i1]) + mpart[2 * PSTR + i1]) + mpart[3 * PSTR + i1];
+        };
+        // row values of the lane's four rows from the ZMP it holds (rows that do not exist: +inf)
+        auto row_vals = [&](double &s00, double &s01, double &s10, double &s11) {
+            s00 = zm0 - lo0; // row i0          (lower bound)
+            s01 = hi0 - zm0; // row N + i0      (upper bound)
+            s10 = zm1 - lo1;
+            s11 = hi1 - zm1;
+        };
+        // Drop working-set position qq (delete_constraint, eiquadprog.hpp:516-592).
+        auto drop_constraint = [&](int qq) {
+            const int last = iq - 1; // columns qq .. last take part
+            {
+                const double c = (double)(iq - 1 - qq);
+                falg += 6.0 * nn * c + 3.0 * c * (c - 1.0);
+            }
+            // the row of the dropped constraint leaves the active flags
+            {
+                const int src = qq & 63;
+                const int l = __builtin_amdgcn_readlane(qq >= HALF ? A1 : A0, src);
+                const int kk = l < N ? l : l - N, up = l < N ? 0 : 1;
+                if (lane == (kk & 63)) actm &= ~(1u << (2 * (kk >> 6) + up));
+            }
+            if (qq < last) {
+                // g = row qq of T, prefix norms rho_j, coefficients of the closed form
+                const double g0 = (i0 >= qq && i0 <= last) ? Tp[(size_t)i0 * (i0 + 1) / 2 + qq] : 0.0;
+                const double g1 = (i1 >= qq && i1 <= last) ? Tp[(size_t)c1 * (c1 + 1) / 2 + qq] : 0.0;
+                const double p0 = wave_scan(g0 * g0);
+                const double p1 = wave_scan(g1 * g1) + lane63(p0);
+                double rho0 = 0.0, ir0 = 0.0, rho1 = 0.0, ir1 = 0.0;
+                if (p0 > 0.0) sqrt_rsqrt(p0, rho0, ir0);
+                if (p1 > 0.0) sqrt_rsqrt(p1, rho1, ir1);
+                gs[i0] = g0;
+                gs[i1] = g1;
+                ins[i0] = ir0;
+                ins[i1] = ir1;
+                wsync();
+                // column j (qq <= j < last): a_j = g_{j+1} / (rho_{j+1} rho_j), b_j = -rho_j / rho_{j+1};
+                // column last (J only): a = 1 / rho_last, b = 0
+                {
+                    const double gn0 = gs[min(i0 + 1, PSTR - 1)], in0 = ins[min(i0 + 1, PSTR - 1)];
+                    const double gn1 = gs[min(i1 + 1, PSTR - 1)], in1 = ins[min(i1 + 1, PSTR - 1)];
+                    double a0c = 0.0, b0c = 0.0, a1c = 0.0, b1c = 0.0;
+                    if (i0 >= qq && i0 < last) {
+                        a0c = gn0 * (in0 * ir0);
+                        b0c = -rho0 * in0;
+                    } else if (i0 == last) {
+                        a0c = ir0;
+                    }
+                    if (i1 >= qq && i1 < last) {
+                        a1c = gn1 * (in1 * ir1);
+                        b1c = -rho1 * in1;
+                    } else if (i1 == last) {
+                        a1c = ir1;
+                    }
+                    ca[i0] = a0c;
+                    cb[i0] = b0c;
+                    ca[i1] = a1c;
+                    cb[i1] = b1c;
+                }
+                wsync();
+                if (wave < 2) {
+                    // rows of J: wave 0 rows 0..63, wave 1 rows 64..n-1
+                    const int r = wave == 0 ? c0 : c1;
+                    const bool rv = wave == 0 ? v0 : v1;
+                    double *Jr = J + r;
+                    double cj = Jr[(size_t)qq * ldj], q = 0.0;
+                    for (int jb = qq; jb < last; jb += 8) {
+                        double cn[8], gv[8], av[8], bv8[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            const int j = min(jb + e, last - 1);
+                            cn[e] = Jr[(size_t)(j + 1) * ldj];
+                            gv[e] = gs[j];
+                            av[e] = ca[j];
+                            bv8[e] = cb[j];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            if (jb + e < last) {
+                                q = fma(gv[e], cj, q);
+                                const double o = fma(av[e], q, bv8[e] * cn[e]);
+                                if (rv) Jr[(size_t)(jb + e) * ldj] = o;
+                                cj = cn[e];
+                            }
+                        }
+                    }
+                    q = fma(gs[last], cj, q);
+                    if (rv) Jr[(size_t)last * ldj] = ca[last] * q;
+                } else if (wave == 2) {
+                    // rows of T (two per lane); row i > qq moves up to i - 1, row qq goes, and
+                    // so does the last column
+                    double cja = (i0 <= qq) ? Tp[(size_t)qq * (qq + 1) / 2 + min(i0, qq)] : 0.0; // T(i0, qq)
+                    double cjb = 0.0;                                                            // T(i1, qq), i1 > qq always or unused
+                    if (i1 <= qq) cjb = Tp[(size_t)qq * (qq + 1) / 2 + i1];
+                    double qa = 0.0, qb = 0.0;
+                    const int na = i0 > qq ? i0 - 1 : i0, nb = i1 > qq ? i1 - 1 : i1;
+                    const bool wa = i0 != qq && i0 <= last, wb = i1 != qq && i1 <= last;
+                    for (int jb = qq; jb < last; jb += 4) {
+                        double cna[4], cnb[4], gv[4], av[4], bv4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int j = min(jb + e, last - 1);
+                            const size_t cbase = (size_t)(j + 1) * (j + 2) / 2;
+                            const double ta = Tp[cbase + min(i0, j + 1)], tb = Tp[cbase + min(i1, j + 1)];
+                            cna[e] = (i0 <= j + 1) ? ta : 0.0;
+                            cnb[e] = (i1 <= j + 1) ? tb : 0.0;
+                            gv[e] = gs[j];
+                            av[e] = ca[j];
+                            bv4[e] = cb[j];
+                        }
+                        wsync(); // every lane has read columns jb + 1 .. jb + 4 before columns jb .. are overwritten
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int j = jb + e;
+                            if (j < last) {
+                                qa = fma(gv[e], cja, qa);
+                                qb = fma(gv[e], cjb, qb);
+                                const double oa = fma(av[e], qa, bv4[e] * cna[e]), ob = fma(av[e], qb, bv4[e] * cnb[e]);
+                                cja = cna[e];
+                                cjb = cnb[e];
+                                const size_t obase = (size_t)j * (j + 1) / 2;
+                                if (wa && na <= j) Tp[obase + na] = oa;
+                                if (wb && nb <= j) Tp[obase + nb] = ob;
+                            }
+                        }
+                        wsync();
+                    }
+                }
+            }
+            // working-set arrays: positions above qq move down by one (registers, every wave)
+            {
+                const double un0 = shift_down(u0, lane), un1 = shift_down(u1, lane);
+                const int an0 = shift_down(A0, lane), an1 = shift_down(A1, lane);
+                const double ux = bcast(u1, 0);
+                const int ax = __builtin_amdgcn_readlane(A1, 0);
+                if (i0 >= qq) {
+                    u0 = lane == 63 ? ux : un0;
+                    A0 = lane == 63 ? ax : an0;
+                }
+                if (i1 >= qq) {
+                    u1 = lane == 63 ? 0.0 : un1;
+                    A1 = lane == 63 ? 0 : an1;
+                }
+            }
+            iq--;
+            __syncthreads(); // J and T as the next pass reads them
+        };
+
+        __syncthreads();
+        BSTAMP(0);
+        bool done = false;
+        int ip = 0, kip = 0;
+        double sgn = 1.0, ucand = 0.0, s_ip = 0.0;
+        while (!done) { // step 1 (l1)
+            iters++;
+            if (iters > sd.iter_cap) {
+                status = MPCB_ITER_CAP;
+                break;
+            }
+            eval_zmp();
+            BSTAMP(1);
+            falg += 2.0 * mm * nn;
+            double s00, s01, s10, s11;
+            row_vals(s00, s01, s10, s11);
+            exclm = 0xf;
+            // sum of infeasibilities (:255-261) and the most violated row among the rows that
+            // are neither active nor excluded (:279-287), lowest row on ties
+            double psi = 0.0;
+            if (v0) psi += fmin(0.0, s00) + fmin(0.0, s01);
+            if (v1) psi += fmin(0.0, s10) + fmin(0.0, s11);
+            psi = wave_sum(psi);
+            if (fabs(psi) <= sd.psi_thr) {
+                zmp_current = true;
+                break;
+            }
+            uo0 = u0;
+            uo1 = u1;
+            Ao0 = A0;
+            Ao1 = A1;
+            xo0 = x0r;
+            xo1 = x1r;
+            double ssv = 0.0;
+            bool restart;
+            do { // step 2 (l2)
+                restart = false;
+                double bv = DINF;
+                int brow = 0x7fffffff, aux = 0;
+                {
+                    const unsigned ok = validm & ~actm & exclm;
+                    auto consider = [&](double v, int row, unsigned bit) {
+                        if ((ok & bit) && v < ssv && (v < bv || (v == bv && row < brow))) {
+                            bv = v;
+                            brow = row;
+                        }
+                    };
+                    consider(s00, i0, 1u);
+                    consider(s10, i1, 4u);
+                    consider(s01, N + i0, 2u);
+                    consider(s11, N + i1, 8u);
+                }
+                wave_argmin(bv, brow, aux);
+                if (bv < ssv) {
+                    ssv = bv;
+                    ip = brow;
+                    s_ip = bv;
+                }
+                if (ssv >= 0.0) {
+                    zmp_current = true; // x has not moved since the evaluation (or was restored)
+                    done = true;
+                    break;
+                }
+                kip = ip < N ? ip : ip - N;
+                sgn = ip < N ? 1.0 : -1.0;
+                ucand = 0.0;
+                BSTAMP(2);
+                for (;;) { // step 2a (l2a)
+                    passes++;
+                    if (passes > sd.iter_cap) {
+                        status = MPCB_ITER_CAP;
+                        done = true;
+                        break;
+                    }
+                    falg += 2.0 * nn * nn + 2.0 * nn * (nn - iq) + (double)iq * iq;
+                    // ---- d = J' n+ : rows 0 .. kip in four bands, a lane's two columns ------
+                    {
+                        const int band = (kip + BW) / BW, r0 = wave * band, r1 = min(r0 + band, kip + 1);
+                        const double *ja = J + (size_t)c0 * ldj, *jb = J + (size_t)c1 * ldj;
+                        double a0 = 0.0, a1 = 0.0;
+                        for (int rb = r0; rb < r1; rb += 8) {
+                            double av[8], bv8[8], nv[8];
+#pragma unroll
+                            for (int e = 0; e < 8; e++) {
+                                const int r = min(rb + e, r1 - 1);
+                                av[e] = ja[r];
+                                bv8[e] = jb[r];
+                                nv[e] = zc[kip - r];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; e++) {
+                                const double c = rb + e < r1 ? nv[e] : 0.0;
+                                a0 = fma(av[e], c, a0);
+                                a1 = fma(bv8[e], c, a1);
+                            }
+                        }
+                        dpart[wave * PSTR + i0] = sgn * a0;
+                        dpart[wave * PSTR + i1] = sgn * a1;
+                    }
+                    BSTAMP(3);
+                    __syncthreads();
+                    BSTAMP(4);
+                    double d0 = ((dpart[i0] + dpart[PSTR + i0]) + dpart[2 * PSTR + i0]) + dpart[3 * PSTR + i0];
+                    double d1 = ((dpart[i1] + dpart[PSTR + i1]) + dpart[2 * PSTR + i1]) + dpart[3 * PSTR + i1];
+                    d0 = v0 ? d0 : 0.0;
+                    d1 = v1 ? d1 : 0.0;
+                    dsv[i0] = d0;
+                    dsv[i1] = d1;
+                    // last column of the free part with a nonzero d (beyond it z gets nothing)
+                    int jt;
+                    {
+                        const unsigned long long nz0 = __ballot(i0 >= iq && d0 != 0.0);
+                        const unsigned long long nz1 = __ballot(i1 >= iq && d1 != 0.0);
+                        jt = nz1 ? 127 - __builtin_clzll(nz1) : nz0 ? 63 - __builtin_clzll(nz0) : iq - 1;
+                    }
+                    wsync();
+                    // ---- z = J2 d2 over columns iq .. jt in four segments; r = T d1 likewise ----
+                    const int seg = (jt - iq + 1 + BW - 1) / BW;
+                    const int slo = iq + wave * seg, shi = min(slo + seg, jt + 1);
+                    double jb0 = 0.0, jb1 = 0.0; // column slo - 1, kept for the update of column slo
+                    {
+                        double a0 = 0.0, a1 = 0.0;
+                        const double *j0p = J + c0, *j1p = J + c1;
+                        for (int jb = slo; jb < shi; jb += 8) {
+                            double av[8], bv8[8], dv[8];
+#pragma unroll
+                            for (int e = 0; e < 8; e++) {
+                                const int j = min(jb + e, shi - 1);
+                                av[e] = j0p[(size_t)j * ldj];
+                                bv8[e] = j1p[(size_t)j * ldj];
+                                dv[e] = dsv[j];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; e++) {
+                                const double c = jb + e < shi ? dv[e] : 0.0;
+                                a0 = fma(av[e], c, a0);
+                                a1 = fma(bv8[e], c, a1);
+                            }
+                        }
+                        if (slo > iq && slo < shi) {
+                            jb0 = j0p[(size_t)(slo - 1) * ldj];
+                            jb1 = j1p[(size_t)(slo - 1) * ldj];
+                        }
+                        zpart[wave * PSTR + i0] = a0;
+                        zpart[wave * PSTR + i1] = a1;
+                        // r_i = sum_k T(i, k) d_k, k in this wave's quarter of [0, iq)
+                        const int tseg = (iq + BW - 1) / BW, k0 = wave * tseg, k1 = min(k0 + tseg, iq);
+                        double b0 = 0.0, b1 = 0.0;
+                        for (int kb = k0; kb < k1; kb += 8) {
+                            double t0v[8], t1v[8], dv[8];
+#pragma unroll
+                            for (int e = 0; e < 8; e++) {
+                                const int k = min(kb + e, k1 - 1);
+                                const size_t base = (size_t)k * (k + 1) / 2;
+                                t0v[e] = Tp[base + min(i0, k)];
+                                t1v[e] = Tp[base + min(i1, k)];
+                                dv[e] = dsv[k];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; e++) {
+                                const int k = kb + e;
+                                const bool in = k < k1;
+                                b0 = fma((in && i0 <= k) ? t0v[e] : 0.0, dv[e], b0);
+                                b1 = fma((in && i1 <= k) ? t1v[e] : 0.0, dv[e], b1);
+                            }
+                        }
+                        rpart[wave * PSTR + i0] = b0;
+                        rpart[wave * PSTR + i1] = b1;
+                    }
+                    BSTAMP(5);
+                    __syncthreads();
+                    BSTAMP(6);
+                    // ---- step lengths, in every wave ------------------------------------------
+                    const double z0 = ((zpart[i0] + zpart[PSTR + i0]) + zpart[2 * PSTR + i0]) + zpart[3 * PSTR + i0];
+                    const double z1 = ((zpart[i1] + zpart[PSTR + i1]) + zpart[2 * PSTR + i1]) + zpart[3 * PSTR + i1];
+                    double r0v = ((rpart[i0] + rpart[PSTR + i0]) + rpart[2 * PSTR + i0]) + rpart[3 * PSTR + i0];
+                    double r1v = ((rpart[i1] + rpart[PSTR + i1]) + rpart[2 * PSTR + i1]) + rpart[3 * PSTR + i1];
+                    r0v = i0 < iq ? r0v : 0.0;
+                    r1v = i1 < iq ? r1v : 0.0;
+                    const double np0 = (v0 && i0 <= kip) ? sgn * zc[kip - min(i0, kip)] : 0.0;
+                    const double np1 = (v1 && i1 <= kip) ? sgn * zc[kip - min(i1, kip)] : 0.0;
+                    const double zz = wave_sum((v0 ? z0 * z0 : 0.0) + (v1 ? z1 * z1 : 0.0));
+                    const double zn = wave_sum((v0 ? z0 * np0 : 0.0) + (v1 ? z1 * np1 : 0.0));
+                    // step 2b: t1 = min u_k / r_k over r_k > 0, lowest position on ties (:322-334)
+                    double t1 = (i0 < iq && r0v > 0.0) ? u0 / r0v : DINF;
+                    int kpos = i0, aux2 = 0;
+                    {
+                        const double tb = (i1 < iq && r1v > 0.0) ? u1 / r1v : DINF;
+                        if (tb < t1) {
+                            t1 = tb;
+                            kpos = i1;
+                        }
+                    }
+                    wave_argmin(t1, kpos, aux2);
+                    const double t2 = fabs(zz) > EPS ? -s_ip / zn : DINF; // :336-339
+                    const double t = fmin(t1, t2);
+                    BSTAMP(7);
+                    if (t >= DINF) { // :350-356
+                        status = MPCB_INFEASIBLE;
+                        f = DINF;
+                        done = true;
+                        break;
+                    }
+                    if (t2 >= DINF) { // dual step only, then drop (:358-373)
+                        u0 -= t * r0v;
+                        u1 -= t * r1v;
+                        ucand += t;
+                        drop_constraint(kpos);
+                        BSTAMP(10);
+                        continue;
+                    }
+                    // step in primal and dual space (:377-382)
+                    x0r = fma(t, z0, x0r);
+                    x1r = fma(t, z1, x1r);
+                    if (v0) xs[i0] = x0r;
+                    if (v1) xs[i1] = x1r;
+                    f += t * zn * (0.5 * t + ucand);
+                    u0 -= t * r0v;
+                    u1 -= t * r1v;
+                    ucand += t;
+                    if (t == t2) { // full step: add the constraint (:392-426, add_constraint :450-513)
+                        falg += 6.0 * nn * (nn - iq - 1);
+                        // suffix norms nu_j = ||d[j .. jt]||, accumulated from the far end like the
+                        // reference's chain of hypots (a total minus a prefix would cancel)
+                        const double e0 = (i0 >= iq && v0) ? d0 * d0 : 0.0, e1 = (i1 >= iq && v1) ? d1 * d1 : 0.0;
+                        const double sc1 = wave_scan(lane_reverse(e1, lane));
+                        const double sc0 = wave_scan(lane_reverse(e0, lane)) + lane63(sc1);
+                        // norm and reciprocal norm from one rsqrt chain: no division in the coefficients
+                        const double S0 = lane_reverse(sc0, lane), S1 = lane_reverse(sc1, lane);
+                        double nu0 = 0.0, inu0 = 0.0, nu1 = 0.0, inu1 = 0.0;
+                        if (S0 > 0.0) sqrt_rsqrt(S0, nu0, inu0);
+                        if (S1 > 0.0) sqrt_rsqrt(S1, nu1, inu1);
+                        nus[i0] = nu0;
+                        nus[i1] = nu1;
+                        ins[i0] = inu0;
+                        ins[i1] = inu1;
+                        wsync();
+                        const double rho = ufirst(nus[iq]); // new diagonal entry of R
+                        const double irho = ufirst(ins[iq]);
+                        {
+                            const double dm0 = dsv[max(i0 - 1, 0)], im0 = ins[max(i0 - 1, 0)];
+                            const double dm1 = dsv[i1 - 1], im1 = ins[i1 - 1];
+                            double a0c = 0.0, b0c = 0.0, a1c = 0.0, b1c = 0.0;
+                            if (i0 == iq) a0c = inu0;
+                            else if (i0 > iq && i0 <= jt) {
+                                a0c = -dm0 * (im0 * inu0);
+                                b0c = nu0 * im0;
+                            }
+                            if (i1 == iq) a1c = inu1;
+                            else if (i1 > iq && i1 <= jt) {
+                                a1c = -dm1 * (im1 * inu1);
+                                b1c = nu1 * im1;
+                            }
+                            ca[i0] = a0c;
+                            cb[i0] = b0c;
+                            ca[i1] = a1c;
+                            cb[i1] = b1c;
+                        }
+                        wsync();
+                        BSTAMP(8);
+                        // the update: this wave's column segment, from its top down; P starts at
+                        // the partial sums of the segments above
+                        {
+                            double P0 = 0.0, P1 = 0.0;
+                            for (int w2 = BW - 1; w2 > wave; w2--) {
+                                P0 += zpart[w2 * PSTR + i0];
+                                P1 += zpart[w2 * PSTR + i1];
+                            }
+                            double *j0p = J + c0, *j1p = J + c1;
+                            if (slo < shi) {
+                                double cur0 = j0p[(size_t)(shi - 1) * ldj], cur1 = j1p[(size_t)(shi - 1) * ldj];
+                                for (int jtop = shi - 1; jtop >= slo; jtop -= 8) {
+                                    // columns jtop, jtop - 1, ... (at most eight, not below slo); every
+                                    // load of the group is issued before its first store
+                                    double p0v[8], p1v[8], dv[8], av[8], bv8[8];
+#pragma unroll
+                                    for (int e = 0; e < 8; e++) {
+                                        const int j = max(jtop - e, slo);
+                                        const int jm = max(j - 1, 0);
+                                        p0v[e] = j0p[(size_t)jm * ldj];
+                                        p1v[e] = j1p[(size_t)jm * ldj];
+                                        dv[e] = dsv[j];
+                                        av[e] = ca[j];
+                                        bv8[e] = cb[j];
+                                    }
+#pragma unroll
+                                    for (int e = 0; e < 8; e++) {
+                                        const int j = jtop - e;
+                                        if (j >= slo) {
+                                            const double prev0 = j == slo ? jb0 : p0v[e], prev1 = j == slo ? jb1 : p1v[e];
+                                            P0 = fma(cur0, dv[e], P0);
+                                            P1 = fma(cur1, dv[e], P1);
+                                            const double o0 = fma(av[e], P0, bv8[e] * prev0);
+                                            const double o1 = fma(av[e], P1, bv8[e] * prev1);
+                                            if (v0) j0p[(size_t)j * ldj] = o0;
+                                            if (v1) j1p[(size_t)j * ldj] = o1;
+                                            cur0 = prev0;
+                                            cur1 = prev1;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        if (rho <= EPS * R_norm) {
+                            // degenerate (:400-418): exclude ip, restore u, A and x of step 1,
+                            // choose again
+                            if (lane == (kip & 63)) exclm &= ~(1u << (2 * (kip >> 6) + (ip < N ? 0 : 1)));
+                            if (i0 < iq) {
+                                u0 = uo0;
+                                A0 = Ao0;
+                            }
+                            if (i1 < iq) {
+                                u1 = uo1;
+                                A1 = Ao1;
+                            }
+                            x0r = xo0;
+                            x1r = xo1;
+                            if (v0) xs[i0] = x0r;
+                            if (v1) xs[i1] = x1r;
+                            actm = 0;
+                            for (int a = 0; a < iq; a++) {
+                                const int l = __builtin_amdgcn_readlane(a >= HALF ? A1 : A0, a & 63);
+                                const int kk = l < N ? l : l - N;
+                                if (lane == (kk & 63)) actm |= 1u << (2 * (kk >> 6) + (l < N ? 0 : 1));
+                            }
+                            __syncthreads(); // J as the next pass reads it
+                            restart = true;
+                            break;
+                        }
+                        R_norm = fmax(R_norm, rho);
+                        // new column of T = [-r; 1] / rho  (wave 0 stores it)
+                        if (wave == 0) {
+                            const size_t base = (size_t)iq * (iq + 1) / 2;
+                            if (i0 < iq) Tp[base + i0] = -r0v * irho;
+                            if (i1 < iq) Tp[base + i1] = -r1v * irho;
+                            if (i0 == iq) Tp[base + i0] = irho;
+                            if (i1 == iq) Tp[base + i1] = irho;
+                        }
+                        if (i0 == iq) {
+                            u0 = ucand;
+                            A0 = ip;
+                        }
+                        if (i1 == iq) {
+                            u1 = ucand;
+                            A1 = ip;
+                        }
+                        if (lane == (kip & 63)) actm |= 1u << (2 * (kip >> 6) + (ip < N ? 0 : 1));
+                        iq++;
+                        BSTAMP(9);
+                        break; // goto l1 (its barrier publishes J and T)
+                    }
+                    // partial step (:434-446): drop the blocking constraint, re-evaluate row ip
+                    drop_constraint(kpos);
+                    BSTAMP(10);
+                    {
+                        const double t0 = zc[kip - min(i0, kip)], t1b = zc[kip - min(i1, kip)];
+                        const double acc = wave_sum((i0 <= kip ? t0 * x0r : 0.0) + ((v1 && i1 <= kip) ? t1b * x1r : 0.0));
+                        const double zk = bcast((kip >= HALF) ? zf1 : zf0, kip & 63) + acc;
+                        const double lok = bcast((kip >= HALF) ? lo1 : lo0, kip & 63);
+                        const double hik = bcast((kip >= HALF) ? hi1 : hi0, kip & 63);
+                        s_ip = ip < N ? zk - lok : hik - zk;
+                    }
+                    BSTAMP(11);
+                }
+            } while (restart);
+        }
+
+        // ---- outputs ---------------------------------------------------------------
+#ifdef MPCB_STAMPS
+        BSTAMP(12);
+        stamp_acc[13] = passes;
+        stamp_acc[14] = iters;
+        if (tid == 0 && sd.dbg)
+            for (int i = 0; i < 16; i++) sd.dbg[(size_t)inst * 16 + i] = stamp_acc[i];
+#endif
+        const bool solved = status == MPCB_OK || status == MPCB_ITER_CAP;
+        if (tid == 0) {
+            if (out.cost) out.cost[inst] = f;
+            if (out.status) out.status[inst] = status;
+            if (out.iters) out.iters[inst] = iters;
+            if (out.n_active) out.n_active[inst] = iq;
+            if (out.alg_flops) out.alg_flops[inst] = falg;
+        }
+        if (wave == 0 && (out.active_idx || out.multipliers)) {
+            for (int a = lane; a < out.active_stride; a += HALF) {
+                int av = -1;
+                double uv = 0.0;
+                if (a < 2 * HALF) {
+                    const int as = a >= HALF ? A1 : A0;
+                    const double us = a >= HALF ? u1 : u0;
+                    if (a < iq) {
+                        av = as;
+                        uv = us;
+                    }
+                }
+                if (out.active_idx) out.active_idx[(size_t)inst * out.active_stride + a] = av;
+                if (out.multipliers) out.multipliers[(size_t)inst * out.active_stride + a] = uv;
+            }
+        }
+        if (!solved) {
+            x0r = x1r = 0.0;
+            if (v0) xs[i0] = 0.0;
+            if (v1) xs[i1] = 0.0;
+        }
+        __syncthreads();
+        if (!zmp_current || !solved) eval_zmp();
+        else __syncthreads();
+        if (wave == 0) {
+            auto put = [&](int k, double xk, double zk, double lok, double hik) {
+                const size_t o = (size_t)inst * N + k;
+                if (out.jerk_x) out.jerk_x[o] = xk;
+                if (out.zmp_x) out.zmp_x[o] = solved ? zk : 0.0;
+                if (out.zmp_y) out.zmp_y[o] = 0.0;
+                if (out.min_margin) out.min_margin[o] = solved ? fmin(zk - lok, hik - zk) : 0.0;
+            };
+            if (v0) put(i0, x0r, zm0, lo0, hi0);
+            if (v1) put(i1, x1r, zm1, lo1, hi1);
+        }
+        if (out.com_x || out.com_y || out.com_xd || out.com_yd) {
+            // computeCOMtrajectory (MPCPlanner.cpp:196-209): Sx x0 + Su jerk with the Toeplitz columns
+            for (int k = tid; k < N; k += BT) {
+                const size_t o = (size_t)inst * N + k;
+                const double *pr = ws.xpx + (size_t)k * 3, *vr = ws.xvx + (size_t)k * 3;
+                double cx = pr[0] * w4[0] + pr[1] * w4[1] + pr[2] * w4[2];
+                double vx = vr[0] * w4[0] + vr[1] * w4[1] + vr[2] * w4[2];
+                for (int j = 0; j <= k; j++) {
+                    cx += ws.xp_col[k - j] * xs[j];
+                    vx += ws.xv_col[k - j] * xs[j];
+                }
+                if (out.com_x) out.com_x[o] = solved ? cx : 0.0;
+                if (out.com_y) out.com_y[o] = 0.0;
+                if (out.com_xd) out.com_xd[o] = solved ? vx : 0.0;
+                if (out.com_yd) out.com_yd[o] = 0.0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+} // namespace
+
+size_t box_dense_lds_bytes(const DevSetup &sd) {
+    const size_t n = sd.N;
+    const size_t doubles = n * (n | 1) + n * (n + 1) / 2 + PSTR + 8 * PSTR + 1 + 4 * BW * PSTR;
+    return doubles * 8;
+}
+
+bool box_dense_applies(const DevSetup &sd) {
+    return sd.form == MPCB_BOX_1D && sd.N <= 2 * HALF && box_dense_lds_bytes(sd) <= 160 * 1024 - 512;
+}
+
+hipError_t launch_box_dense(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, const DenseWs &ws,
+                            int blocks, hipStream_t stream) {
+    if (blocks <= 0) return hipSuccess;
+    const size_t shmem = box_dense_lds_bytes(sd);
+    const void *fn = reinterpret_cast<const void *>(box_dense_kernel);
+    if (shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    void *args[] = {(void *)&sd, (void *)&in, (void *)&out, (void *)&ws};
+    return hipLaunchKernel(fn, dim3(blocks), dim3(BT), args, shmem, stream);
+}
+
+} // namespace mpcb

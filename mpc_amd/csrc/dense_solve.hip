@@ -1045,6 +1045,10 @@ size_t dense_lds_bytes(const DevSetup &sd, bool ldsj) {
 } // namespace
 
 size_t dense_lds_bytes_needed(const DevSetup &sd, bool *in_lds) {
+    if (box_dense_applies(sd)) {
+        if (in_lds) *in_lds = true;
+        return box_dense_lds_bytes(sd) + 256;
+    }
     // 160 KB of LDS per workgroup at most; keep a margin for the static part
     const bool ldsj = dense_lds_bytes(sd, true) <= 160 * 1024 - 256;
     if (in_lds) *in_lds = ldsj;
@@ -1059,6 +1063,7 @@ hipError_t launch_list_all(const DenseWs &ws, int B, hipStream_t stream) {
 hipError_t launch_dense(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, const DenseWs &ws,
                         int blocks, hipStream_t stream) {
     if (blocks <= 0) return hipSuccess;
+    if (box_dense_applies(sd)) return launch_box_dense(sd, in, out, ws, blocks, stream);
     const bool poly = sd.form != MPCB_BOX_1D;
     // 160 KB of LDS per workgroup at most; keep a margin for the static part
     const bool ldsj = dense_lds_bytes(sd, true) <= 160 * 1024 - 256;

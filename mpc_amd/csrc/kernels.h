@@ -66,6 +66,14 @@ hipError_t launch_list_all(const DenseWs &ws, int B, hipStream_t stream);
 hipError_t launch_dense(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, const DenseWs &ws,
                         int blocks, hipStream_t stream);
 
+// The LDS-resident low-latency variant of the dense kernel for small box problems
+// (box_dense.hip): whether it covers this shape, its LDS need, and its launcher (same
+// contract as launch_dense).
+bool box_dense_applies(const DevSetup &sd);
+size_t box_dense_lds_bytes(const DevSetup &sd);
+hipError_t launch_box_dense(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, const DenseWs &ws,
+                            int blocks, hipStream_t stream);
+
 // LDS bytes one workgroup of the dense kernel needs for this shape (dynamic + static part);
 // *in_lds: whether it keeps J and R in LDS, in which case ws.J / ws.R are never touched.
 size_t dense_lds_bytes_needed(const DevSetup &sd, bool *in_lds);
