@@ -161,24 +161,12 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
             const int band = (N + BW - 1) / BW, j0 = wave * band;
             double a0 = wave == 0 ? zf0 : 0.0, a1 = wave == 0 ? zf1 : 0.0;
             const int jend = min(j0 + band, N);
-            // eight columns' loads are issued together (clamped, the tail masked): with one wave
-            // per SIMD nothing else hides the LDS latency
-            for (int jb = j0; jb < jend; jb += 8) {
-                double xv[8], t0v[8], t1v[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int j = min(jb + e, jend - 1);
-                    xv[e] = xs[j];
-                    t0v[e] = zc[max(c0 - j, 0)];
-                    t1v[e] = zc[max(c1 - j, 0)];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int j = jb + e;
-                    const bool in = j < jend;
-                    a0 = fma((in && j <= i0) ? t0v[e] : 0.0, xv[e], a0);
-                    a1 = fma((in && j <= i1) ? t1v[e] : 0.0, xv[e], a1);
-                }
+#pragma unroll 4
+            for (int j = j0; j < jend; j++) {
+                const double xj = xs[j];
+                const double t0 = zc[max(c0 - j, 0)], t1 = zc[max(c1 - j, 0)];
+                a0 = fma(j <= i0 ? t0 : 0.0, xj, a0);
+                a1 = fma(j <= i1 ? t1 : 0.0, xj, a1);
             }
             mpart[wave * PSTR + i0] = a0;
             mpart[wave * PSTR + i1] = a1;
@@ -251,25 +239,28 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     const bool rv = wave == 0 ? v0 : v1;
                     double *Jr = J + r;
                     double cj = Jr[(size_t)qq * ldj], q = 0.0;
-                    for (int jb = qq; jb < last; jb += 8) {
-                        double cn[8], gv[8], av[8], bv8[8];
+                    int j = qq;
+                    for (; j + 4 <= last; j += 4) {
+                        double cn[4], o[4];
 #pragma unroll
-                        for (int e = 0; e < 8; e++) {
-                            const int j = min(jb + e, last - 1);
-                            cn[e] = Jr[(size_t)(j + 1) * ldj];
-                            gv[e] = gs[j];
-                            av[e] = ca[j];
-                            bv8[e] = cb[j];
-                        }
+                        for (int e = 0; e < 4; e++) cn[e] = Jr[(size_t)(j + e + 1) * ldj];
 #pragma unroll
-                        for (int e = 0; e < 8; e++) {
-                            if (jb + e < last) {
-                                q = fma(gv[e], cj, q);
-                                const double o = fma(av[e], q, bv8[e] * cn[e]);
-                                if (rv) Jr[(size_t)(jb + e) * ldj] = o;
-                                cj = cn[e];
-                            }
+                        for (int e = 0; e < 4; e++) {
+                            q = fma(gs[j + e], cj, q);
+                            o[e] = fma(ca[j + e], q, cb[j + e] * cn[e]);
+                            cj = cn[e];
                         }
+                        if (rv) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) Jr[(size_t)(j + e) * ldj] = o[e];
+                        }
+                    }
+                    for (; j < last; j++) {
+                        const double cn = Jr[(size_t)(j + 1) * ldj];
+                        q = fma(gs[j], cj, q);
+                        const double o = fma(ca[j], q, cb[j] * cn);
+                        if (rv) Jr[(size_t)j * ldj] = o;
+                        cj = cn;
                     }
                     q = fma(gs[last], cj, q);
                     if (rv) Jr[(size_t)last * ldj] = ca[last] * q;
@@ -413,21 +404,11 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                         const int band = (kip + BW) / BW, r0 = wave * band, r1 = min(r0 + band, kip + 1);
                         const double *ja = J + (size_t)c0 * ldj, *jb = J + (size_t)c1 * ldj;
                         double a0 = 0.0, a1 = 0.0;
-                        for (int rb = r0; rb < r1; rb += 8) {
-                            double av[8], bv8[8], nv[8];
-#pragma unroll
-                            for (int e = 0; e < 8; e++) {
-                                const int r = min(rb + e, r1 - 1);
-                                av[e] = ja[r];
-                                bv8[e] = jb[r];
-                                nv[e] = zc[kip - r];
-                            }
-#pragma unroll
-                            for (int e = 0; e < 8; e++) {
-                                const double c = rb + e < r1 ? nv[e] : 0.0;
-                                a0 = fma(av[e], c, a0);
-                                a1 = fma(bv8[e], c, a1);
-                            }
+#pragma unroll 4
+                        for (int r = r0; r < r1; r++) {
+                            const double nr = zc[kip - r];
+                            a0 = fma(ja[r], nr, a0);
+                            a1 = fma(jb[r], nr, a1);
                         }
                         dpart[wave * PSTR + i0] = sgn * a0;
                         dpart[wave * PSTR + i1] = sgn * a1;
@@ -456,21 +437,11 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     {
                         double a0 = 0.0, a1 = 0.0;
                         const double *j0p = J + c0, *j1p = J + c1;
-                        for (int jb = slo; jb < shi; jb += 8) {
-                            double av[8], bv8[8], dv[8];
-#pragma unroll
-                            for (int e = 0; e < 8; e++) {
-                                const int j = min(jb + e, shi - 1);
-                                av[e] = j0p[(size_t)j * ldj];
-                                bv8[e] = j1p[(size_t)j * ldj];
-                                dv[e] = dsv[j];
-                            }
-#pragma unroll
-                            for (int e = 0; e < 8; e++) {
-                                const double c = jb + e < shi ? dv[e] : 0.0;
-                                a0 = fma(av[e], c, a0);
-                                a1 = fma(bv8[e], c, a1);
-                            }
+#pragma unroll 4
+                        for (int j = slo; j < shi; j++) {
+                            const double dj = dsv[j];
+                            a0 = fma(j0p[(size_t)j * ldj], dj, a0);
+                            a1 = fma(j1p[(size_t)j * ldj], dj, a1);
                         }
                         if (slo > iq && slo < shi) {
                             jb0 = j0p[(size_t)(slo - 1) * ldj];
@@ -481,23 +452,13 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                         // r_i = sum_k T(i, k) d_k, k in this wave's quarter of [0, iq)
                         const int tseg = (iq + BW - 1) / BW, k0 = wave * tseg, k1 = min(k0 + tseg, iq);
                         double b0 = 0.0, b1 = 0.0;
-                        for (int kb = k0; kb < k1; kb += 8) {
-                            double t0v[8], t1v[8], dv[8];
-#pragma unroll
-                            for (int e = 0; e < 8; e++) {
-                                const int k = min(kb + e, k1 - 1);
-                                const size_t base = (size_t)k * (k + 1) / 2;
-                                t0v[e] = Tp[base + min(i0, k)];
-                                t1v[e] = Tp[base + min(i1, k)];
-                                dv[e] = dsv[k];
-                            }
-#pragma unroll
-                            for (int e = 0; e < 8; e++) {
-                                const int k = kb + e;
-                                const bool in = k < k1;
-                                b0 = fma((in && i0 <= k) ? t0v[e] : 0.0, dv[e], b0);
-                                b1 = fma((in && i1 <= k) ? t1v[e] : 0.0, dv[e], b1);
-                            }
+#pragma unroll 4
+                        for (int k = k0; k < k1; k++) {
+                            const size_t base = (size_t)k * (k + 1) / 2;
+                            const double dk = dsv[k];
+                            const double t0 = Tp[base + min(i0, k)], t1 = Tp[base + min(i1, k)];
+                            b0 = fma(i0 <= k ? t0 : 0.0, dk, b0);
+                            b1 = fma(i1 <= k ? t1 : 0.0, dk, b1);
                         }
                         rpart[wave * PSTR + i0] = b0;
                         rpart[wave * PSTR + i1] = b1;
@@ -604,35 +565,18 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                             double *j0p = J + c0, *j1p = J + c1;
                             if (slo < shi) {
                                 double cur0 = j0p[(size_t)(shi - 1) * ldj], cur1 = j1p[(size_t)(shi - 1) * ldj];
-                                for (int jtop = shi - 1; jtop >= slo; jtop -= 8) {
-                                    // columns jtop, jtop - 1, ... (at most eight, not below slo); every
-                                    // load of the group is issued before its first store
-                                    double p0v[8], p1v[8], dv[8], av[8], bv8[8];
-#pragma unroll
-                                    for (int e = 0; e < 8; e++) {
-                                        const int j = max(jtop - e, slo);
-                                        const int jm = max(j - 1, 0);
-                                        p0v[e] = j0p[(size_t)jm * ldj];
-                                        p1v[e] = j1p[(size_t)jm * ldj];
-                                        dv[e] = dsv[j];
-                                        av[e] = ca[j];
-                                        bv8[e] = cb[j];
-                                    }
-#pragma unroll
-                                    for (int e = 0; e < 8; e++) {
-                                        const int j = jtop - e;
-                                        if (j >= slo) {
-                                            const double prev0 = j == slo ? jb0 : p0v[e], prev1 = j == slo ? jb1 : p1v[e];
-                                            P0 = fma(cur0, dv[e], P0);
-                                            P1 = fma(cur1, dv[e], P1);
-                                            const double o0 = fma(av[e], P0, bv8[e] * prev0);
-                                            const double o1 = fma(av[e], P1, bv8[e] * prev1);
-                                            if (v0) j0p[(size_t)j * ldj] = o0;
-                                            if (v1) j1p[(size_t)j * ldj] = o1;
-                                            cur0 = prev0;
-                                            cur1 = prev1;
-                                        }
-                                    }
+                                for (int j = shi - 1; j >= slo; j--) {
+                                    const bool bottom = j == slo;
+                                    const double prev0 = bottom ? jb0 : j0p[(size_t)(j - 1) * ldj];
+                                    const double prev1 = bottom ? jb1 : j1p[(size_t)(j - 1) * ldj];
+                                    const double dj = dsv[j], aj = ca[j], bj = cb[j];
+                                    P0 = fma(cur0, dj, P0);
+                                    P1 = fma(cur1, dj, P1);
+                                    const double o0 = fma(aj, P0, bj * prev0), o1 = fma(aj, P1, bj * prev1);
+                                    if (v0) j0p[(size_t)j * ldj] = o0;
+                                    if (v1) j1p[(size_t)j * ldj] = o1;
+                                    cur0 = prev0;
+                                    cur1 = prev1;
                                 }
                             }
                         }
