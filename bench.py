@@ -35,6 +35,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from mpc_amd import batches, planner as P  # noqa: E402
+from mpc_amd.provenance import kernel_source_sha  # noqa: E402
 
 # fp64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) per clock at the
 # 2.4 GHz maximum clock of MI355X_MICROARCH's chip table.
@@ -52,6 +53,8 @@ def measured_profile(workload):
         return None, None
     try:
         data = json.load(open(files[-1]))
+        if data.get("kernel_source_sha") != kernel_source_sha():
+            return None, os.path.relpath(files[-1], ROOT)  # counters of other code: not used
         kernels = data.get("kernels", {})
         name = max(kernels, key=lambda k: kernels[k].get("avg_us", 0.0) * kernels[k].get("calls", 0))
         k = dict(kernels[name])
@@ -177,8 +180,15 @@ class ReplanningWorkload:
         return self.out[0]
 
     def alg_flops(self):
-        # the last stage's count stands in for every stage (stages are statistically alike)
-        return float(self.out[0]["alg_flops"].sum().item()) * self.STAGES
+        """Sum over all stages: the sweep is deterministic, so STAGES one-stage sweeps on the
+        evolving state (outside the timed region) visit exactly the stages of the timed sweep."""
+        for k, t in self.pristine.items():
+            self.prepared[2][k].copy_(t)
+        total = 0.0
+        for _ in range(self.STAGES):
+            self.pl.replan_sweep(self.prepared, 1, out=self.out, record=False)
+            total += float(self.out[0]["alg_flops"].sum().item())
+        return total
 
     def describe(self):
         return {"workload": self.name, "rollouts_per_gpu": self.B, "stages": self.STAGES, "horizon": self.N,
@@ -207,10 +217,17 @@ class DecoupledWorkload:
         self.B = B
         self.name = "decoupled"
         self.inputs = batches.decoupled_batch(B, N=self.N, steps=10, first=first)
+        # one handle per axis: a handle is bound to one stream at a time, and the two axes of a
+        # pair are independent QPs, so they run on two streams (the Y axis fills the CUs that the
+        # X axis' second-stage kernel, one workgroup per CU, leaves idle)
         self.pl = P.BatchedPlanner(self.N, formulation=P.BOX_1D, weight_R=1.0, device=dev)
+        self.pl_y = P.BatchedPlanner(self.N, formulation=P.BOX_1D, weight_R=1.0, device=dev)
+        self.side = torch.cuda.Stream(device=dev)
+        self.ev_fork = torch.cuda.Event()
+        self.ev_join = torch.cuda.Event()
         i = self.inputs
         self.px = self.pl.prepare_box(i["x0"], i["xmin"], i["xmax"])
-        self.py = self.pl.prepare_box(i["y0"], i["ymin"], i["ymax"])
+        self.py = self.pl_y.prepare_box(i["y0"], i["ymin"], i["ymax"])
         self.outx = self.pl._alloc_outputs(B, P.ALL_OUTPUTS)
         self.outy = self.pl._alloc_outputs(B, P.ALL_OUTPUTS)
         self.units = B  # one unit = one X/Y pair (two scalar QPs)
@@ -218,8 +235,13 @@ class DecoupledWorkload:
         self.alg_bytes = 2 * B * (8 * (3 + 2 * self.N + 2 * self.N + 1) + 4 * (self.pl.active_stride + 4))
 
     def step(self):
-        self.pl.solve_box_prepared(self.px, out=self.outx)
-        self.pl.solve_box_prepared(self.py, out=self.outy)
+        main = torch.cuda.current_stream()
+        self.ev_fork.record(main)
+        self.side.wait_event(self.ev_fork)
+        self.pl.solve_box_prepared(self.px, out=self.outx, stream=main)
+        self.pl_y.solve_box_prepared(self.py, out=self.outy, stream=self.side)
+        self.ev_join.record(self.side)
+        main.wait_event(self.ev_join)
 
     def results(self):
         return self.outy[0]
@@ -232,10 +254,9 @@ class DecoupledWorkload:
                 "variables": 100, "constraints": 200, "weights": {"R": 1.0}, "seed": batches.SEED}
 
     def second_stage_instances(self):
-        self.pl.solve_box_prepared(self.px, out=self.outx)
-        nx = self.pl.last_handover_count()
-        self.pl.solve_box_prepared(self.py, out=self.outy)
-        return {"x_axis": nx, "y_axis": self.pl.last_handover_count()}
+        self.step()
+        torch.cuda.synchronize()
+        return {"x_axis": self.pl.last_handover_count(), "y_axis": self.pl_y.last_handover_count()}
 
     def feasible_subset(self, steps=10):
         """Throughput over the pairs whose two QPs are feasible (the infeasible X-axis draws, kept in
@@ -245,20 +266,20 @@ class DecoupledWorkload:
         n = int(ok.sum())
         if n == 0:
             return None
-        px = self.pl.prepare_box(i["x0"], i["xmin"], i["xmax"])
-        py = self.pl.prepare_box(i["y0"], i["ymin"], i["ymax"])
-        ox = self.pl._alloc_outputs(n, P.ALL_OUTPUTS)
-        oy = self.pl._alloc_outputs(n, P.ALL_OUTPUTS)
+        keep = (self.px, self.py, self.outx, self.outy)
+        self.px = self.pl.prepare_box(i["x0"], i["xmin"], i["xmax"])
+        self.py = self.pl_y.prepare_box(i["y0"], i["ymin"], i["ymax"])
+        self.outx = self.pl._alloc_outputs(n, P.ALL_OUTPUTS)
+        self.outy = self.pl._alloc_outputs(n, P.ALL_OUTPUTS)
         for _ in range(2):
-            self.pl.solve_box_prepared(px, out=ox)
-            self.pl.solve_box_prepared(py, out=oy)
+            self.step()
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(steps):
-            self.pl.solve_box_prepared(px, out=ox)
-            self.pl.solve_box_prepared(py, out=oy)
+            self.step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / steps
+        self.px, self.py, self.outx, self.outy = keep
         return {"pairs": n, "value": n / dt, "unit": "solves/s", "ms_per_step": dt * 1e3}
 
     def cpu_baseline(self, threads, sample):
@@ -381,20 +402,27 @@ def main():
             "config": wl.describe(),
             "roofline": {
                 "bound": "fp64_vector",
-                "achieved": achieved_tf,
+                # filled in below from the counter profile of THIS source (fp64 operations the
+                # dominant kernel really issued / its duration measured in this run); stays null
+                # when no profile of the current kernel sources is committed
+                "achieved": None,
                 "peak": peak_tf,
                 "unit": "TFLOP/s",
-                "frac": achieved_tf / peak_tf,
+                "frac": None,
                 "traffic": None,
-                "note": "achieved = operations of the dense dual active-set method along each "
-                        "instance's pivot sequence / average kernel duration; the kernel executes "
-                        "far fewer operations than that (structure-exploiting formulation)",
                 "kernel_ms": kernel_s * 1e3,
-                "alg_gflop_per_launch": alg_flops / wl.launches / 1e9,
-                "hbm_achieved_GBs": wl.alg_bytes / wl.launches / kernel_s / 1e9,
-                "hbm_frac": wl.alg_bytes / wl.launches / kernel_s / 1e9 / HBM_PEAK_GBS,
                 "peak_basis": "%d CUs x %.2f GHz x %d fp64 flop/clk/CU" % (cus, clk / 1e9,
                                                                          FP64_FLOP_PER_CLK_PER_CU),
+                "hbm_achieved_GBs": wl.alg_bytes / wl.launches / kernel_s / 1e9,
+                "hbm_frac": wl.alg_bytes / wl.launches / kernel_s / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": wl.alg_bytes / wl.launches,
+                # speed of the algorithm, NOT utilisation: operations the dense dual active-set
+                # method (the reference's) would spend along each instance's pivot sequence, per
+                # second of this kernel.  The kernel avoids almost all of them, so the ratio to
+                # the peak exceeds 1.
+                "alg_gflop_per_launch": alg_flops / wl.launches / 1e9,
+                "alg_tflops": achieved_tf,
+                "alg_speed_vs_peak": achieved_tf / peak_tf,
             },
             "solver": {
                 "status_counts": np.bincount(status, minlength=4).tolist(),
@@ -414,27 +442,33 @@ def main():
         if hasattr(wl, "feasible_subset"):
             line["feasible_subset"] = wl.feasible_subset()
         prof, prof_file = measured_profile(args.workload)
-        if prof is not None:
-            r = line["roofline"]
+        r = line["roofline"]
+        r["kernel_source_sha"] = kernel_source_sha()
+        if prof is None:
+            r["note"] = ("no counter profile of the current kernel sources under profiles/ (%s): executed "
+                         "flops and HBM traffic unknown for this run" % (prof_file or "none found"))
+        else:
+            r["profile_source"] = prof_file
+            r["profiled_kernel"] = prof.get("kernel")
+            r["profiled_kernel_avg_ms"] = (prof.get("avg_us") or 0.0) / 1e3 or None
             r["traffic"] = prof.get("hbm_traffic_bytes_per_launch")
-            r["traffic_unit"] = "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)"
-            r["algorithmic_bytes_per_launch"] = wl.alg_bytes / wl.launches
-            r["executed_f64_gflop_per_launch"] = (prof.get("executed_f64_flops_per_launch") or 0.0) / 1e9 or None
-            if r["executed_f64_gflop_per_launch"] and prof.get("avg_us"):
-                # hardware utilisation proper: fp64 operations the kernel really issued (FMA = 2)
-                # over its profiled duration, against the same vector peak
-                ex = r["executed_f64_gflop_per_launch"] / (prof["avg_us"] * 1e-6) / 1e3
-                r["executed_tflops"] = ex
-                r["executed_frac"] = ex / peak_tf
+            r["traffic_unit"] = "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), rocprofv3 pass of the same source"
+            ex = prof.get("executed_f64_flops_per_launch")
+            # the counters belong to the profiled batch; scale to this run's units
+            scale = wl.units / wl.launches / max(1.0, float(prof.get("units_per_launch") or wl.units / wl.launches))
+            if ex:
+                r["executed_f64_gflop_per_launch"] = ex * scale / 1e9
+                r["achieved"] = ex * scale / kernel_s / 1e12
+                r["frac"] = r["achieved"] / peak_tf
+                r["note"] = ("achieved = fp64 operations the kernel issued (SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 x 64 "
+                             "lanes, FMA = 2; counter pass of the same kernel sources, see profile_source) / "
+                             "average launch duration measured in this run with HIP events")
             c = prof.get("counters_per_launch", {})
             if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_WAVE_CYCLES"):
                 r["valu_busy_per_wave"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
                 r["wave_wait_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
                 r["fp64_share_of_valu"] = ((c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0) +
                                             c.get("SQ_INSTS_VALU_MUL_F64", 0)) / max(1.0, c.get("SQ_INSTS_VALU", 1.0)))
-            r["profiled_kernel"] = prof.get("kernel")
-            r["profiled_kernel_avg_ms"] = (prof.get("avg_us") or 0.0) / 1e3 or None
-            r["profile_source"] = prof_file
         sample = args.cpu_sample
         if sample < 0:
             sample = 2048 if args.workload == "decoupled" else 192

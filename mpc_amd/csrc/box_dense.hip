@@ -79,26 +79,31 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
     const int tid = threadIdx.x, lane = tid & 63, wave = ufirst(tid >> 6);
     const int N = sd.N, n = N, m = 2 * N, ldj = n | 1;
     // ---- LDS -------------------------------------------------------------------
-    double *J = smem;                                 // n x ldj, column-major
-    double *Tp = J + (size_t)n * ldj;                 // T = R^-1, packed: T(i,k) at k(k+1)/2 + i, i <= k
-    double *xs = Tp + (size_t)n * (n + 1) / 2 + PSTR; // x by index (identical copies written by every wave)
+    // fixed-size arrays first, at compile-time offsets (fewer live address registers), then the
+    // two matrices whose size depends on n
+    double *xs = smem;                                // x by index (identical copies written by every wave)
     double *dsv = xs + PSTR;                          // d by index
-    double *nus = dsv + PSTR;                         // suffix norms of d / prefix norms of g
-    double *ca = nus + PSTR + 1, *cb = ca + PSTR;     // update coefficients per column
+    double *nus = dsv + PSTR;                         // suffix norms of d
+    double *ca = nus + PSTR, *cb = ca + PSTR;         // update coefficients per column
     double *gs = cb + PSTR;                           // row qq of T
-    double *ins = gs + PSTR;                          // reciprocals of nus
-    double *zc = ins + PSTR;                          // Toeplitz column of Zu
+    double *ins = gs + PSTR;                          // reciprocal norms
+    double *d1s = ins + PSTR;                         // d with the free part (positions >= iq) zeroed
+    double *zc = d1s + 2 * PSTR;                      // Toeplitz column of Zu; zc[-PSTR .. -1] are zeros, so
+                                                      // zc[k - j] needs no test for j > k
     double *dpart = zc + PSTR;                        // [BW][PSTR] partial sums of d = J' n+
     double *zpart = dpart + BW * PSTR;                // [BW][PSTR] partial sums of z = J2 d2
     double *rpart = zpart + BW * PSTR;                // [BW][PSTR] partial sums of r = T d1
     double *mpart = rpart + BW * PSTR;                // [BW][PSTR] partial sums of the ZMP
+    double *J = mpart + BW * PSTR;                    // n x ldj, column-major
+    double *Tp = J + n * ldj;                         // T = R^-1, packed: T(i,k) at k(k+1)/2 + i, i <= k
 
     // a lane owns the indices i0 = lane and i1 = lane + 64 of every length-n object
     const int i0 = lane, i1 = lane + HALF;
     const bool v0 = i0 < n, v1 = i1 < n;
     const int c0 = v0 ? i0 : n - 1, c1 = v1 ? i1 : n - 1;
 
-    for (int k = tid; k < N; k += BT) zc[k] = ws.zu_col[k];
+    for (int k = tid; k < 2 * PSTR; k += BT) zc[k - PSTR] = (k >= PSTR && k - PSTR < N) ? ws.zu_col[k - PSTR] : 0.0;
+    for (int k = tid; k < PSTR; k += BT) xs[k] = 0.0; // entries >= n stay zero
     const int count = *ws.count;
     for (int entry = blockIdx.x; entry < count; entry += gridDim.x) {
         const int inst = ws.list[entry];
@@ -120,18 +125,23 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
         const double lo1 = v1 ? in.zmin[(size_t)inst * N + i1] : -DINF, hi1 = v1 ? in.zmax[(size_t)inst * N + i1] : DINF;
         double zf0, zf1; // Zx x0 at the lane's knots
         {
-            const double *a = ws.zx + (size_t)c0 * 3, *b = ws.zx + (size_t)c1 * 3;
+            const double *a = ws.zx + c0 * 3, *b = ws.zx + c1 * 3;
             zf0 = a[0] * w4[0] + a[1] * w4[1] + a[2] * w4[2];
             zf1 = b[0] * w4[0] + b[1] * w4[1] + b[2] * w4[2];
         }
+        // The unrolled sweeps run a few rows / columns past the end of their range with zero
+        // coefficients; what they read there (J's padding row, the start of T) must be finite.
+        for (int idx = tid; idx < n * (n + 1) / 2 + PSTR; idx += BT) Tp[idx] = 0.0;
+        for (int col = tid; col < n; col += BT)
+            for (int row = n; row < ldj; row++) J[col * ldj + row] = 0.0;
         // J = L^-T (eiquadprog.hpp:174-176), x = -G^-1 g0, f = 1/2 g0'x (:188-191)
         for (int idx = tid; idx < n * n; idx += BT) {
             const int col = idx / n, row = idx - col * n;
-            J[(size_t)col * ldj + row] = ws.J1[(size_t)col * N + row];
+            J[col * ldj + row] = ws.J1[col * N + row];
         }
         double x0r, x1r;
         {
-            const double *a = sd.Kx + (size_t)c0 * 4, *b = sd.Kx + (size_t)c1 * 4;
+            const double *a = sd.Kx + c0 * 4, *b = sd.Kx + c1 * 4;
             x0r = a[0] * w4[0] + a[1] * w4[1] + a[2] * w4[2];
             x1r = b[0] * w4[0] + b[1] * w4[1] + b[2] * w4[2];
         }
@@ -158,15 +168,18 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
         // ZMP at the current x: zfree + Zu x, the triangular product cut into four bands of
         // columns (one per wave); ends with every wave holding the sums.  One barrier.
         auto eval_zmp = [&]() {
-            const int band = (N + BW - 1) / BW, j0 = wave * band;
+            // bands of a multiple of four columns; x is zero beyond n and zc beyond the diagonal
+            const int band = 4 * ((N + 4 * BW - 1) / (4 * BW)), j0 = wave * band;
             double a0 = wave == 0 ? zf0 : 0.0, a1 = wave == 0 ? zf1 : 0.0;
-            const int jend = min(j0 + band, N);
-#pragma unroll 4
-            for (int j = j0; j < jend; j++) {
-                const double xj = xs[j];
-                const double t0 = zc[max(c0 - j, 0)], t1 = zc[max(c1 - j, 0)];
-                a0 = fma(j <= i0 ? t0 : 0.0, xj, a0);
-                a1 = fma(j <= i1 ? t1 : 0.0, xj, a1);
+            const int jend = min(j0 + band, (N + 3) & ~3);
+            const double *z0p = zc + i0, *z1p = zc + i1;
+            for (int j = j0; j < jend; j += 4) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const double xj = xs[j + e];
+                    a0 = fma(z0p[-(j + e)], xj, a0);
+                    a1 = fma(z1p[-(j + e)], xj, a1);
+                }
             }
             mpart[wave * PSTR + i0] = a0;
             mpart[wave * PSTR + i1] = a1;
@@ -197,8 +210,8 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
             }
             if (qq < last) {
                 // g = row qq of T, prefix norms rho_j, coefficients of the closed form
-                const double g0 = (i0 >= qq && i0 <= last) ? Tp[(size_t)i0 * (i0 + 1) / 2 + qq] : 0.0;
-                const double g1 = (i1 >= qq && i1 <= last) ? Tp[(size_t)c1 * (c1 + 1) / 2 + qq] : 0.0;
+                const double g0 = (i0 >= qq && i0 <= last) ? Tp[i0 * (i0 + 1) / 2 + qq] : 0.0;
+                const double g1 = (i1 >= qq && i1 <= last) ? Tp[c1 * (c1 + 1) / 2 + qq] : 0.0;
                 const double p0 = wave_scan(g0 * g0);
                 const double p1 = wave_scan(g1 * g1) + lane63(p0);
                 double rho0 = 0.0, ir0 = 0.0, rho1 = 0.0, ir1 = 0.0;
@@ -238,12 +251,12 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     const int r = wave == 0 ? c0 : c1;
                     const bool rv = wave == 0 ? v0 : v1;
                     double *Jr = J + r;
-                    double cj = Jr[(size_t)qq * ldj], q = 0.0;
+                    double cj = Jr[qq * ldj], q = 0.0;
                     int j = qq;
                     for (; j + 4 <= last; j += 4) {
                         double cn[4], o[4];
 #pragma unroll
-                        for (int e = 0; e < 4; e++) cn[e] = Jr[(size_t)(j + e + 1) * ldj];
+                        for (int e = 0; e < 4; e++) cn[e] = Jr[(j + e + 1) * ldj];
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
                             q = fma(gs[j + e], cj, q);
@@ -252,24 +265,24 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                         }
                         if (rv) {
 #pragma unroll
-                            for (int e = 0; e < 4; e++) Jr[(size_t)(j + e) * ldj] = o[e];
+                            for (int e = 0; e < 4; e++) Jr[(j + e) * ldj] = o[e];
                         }
                     }
                     for (; j < last; j++) {
-                        const double cn = Jr[(size_t)(j + 1) * ldj];
+                        const double cn = Jr[(j + 1) * ldj];
                         q = fma(gs[j], cj, q);
                         const double o = fma(ca[j], q, cb[j] * cn);
-                        if (rv) Jr[(size_t)j * ldj] = o;
+                        if (rv) Jr[j * ldj] = o;
                         cj = cn;
                     }
                     q = fma(gs[last], cj, q);
-                    if (rv) Jr[(size_t)last * ldj] = ca[last] * q;
+                    if (rv) Jr[last * ldj] = ca[last] * q;
                 } else if (wave == 2) {
                     // rows of T (two per lane); row i > qq moves up to i - 1, row qq goes, and
                     // so does the last column
-                    double cja = (i0 <= qq) ? Tp[(size_t)qq * (qq + 1) / 2 + min(i0, qq)] : 0.0; // T(i0, qq)
+                    double cja = (i0 <= qq) ? Tp[qq * (qq + 1) / 2 + min(i0, qq)] : 0.0; // T(i0, qq)
                     double cjb = 0.0;                                                            // T(i1, qq), i1 > qq always or unused
-                    if (i1 <= qq) cjb = Tp[(size_t)qq * (qq + 1) / 2 + i1];
+                    if (i1 <= qq) cjb = Tp[qq * (qq + 1) / 2 + i1];
                     double qa = 0.0, qb = 0.0;
                     const int na = i0 > qq ? i0 - 1 : i0, nb = i1 > qq ? i1 - 1 : i1;
                     const bool wa = i0 != qq && i0 <= last, wb = i1 != qq && i1 <= last;
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
                             const int j = min(jb + e, last - 1);
-                            const size_t cbase = (size_t)(j + 1) * (j + 2) / 2;
+                            const int cbase = (j + 1) * (j + 2) / 2;
                             const double ta = Tp[cbase + min(i0, j + 1)], tb = Tp[cbase + min(i1, j + 1)];
                             cna[e] = (i0 <= j + 1) ? ta : 0.0;
                             cnb[e] = (i1 <= j + 1) ? tb : 0.0;
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                                 const double oa = fma(av[e], qa, bv4[e] * cna[e]), ob = fma(av[e], qb, bv4[e] * cnb[e]);
                                 cja = cna[e];
                                 cjb = cnb[e];
-                                const size_t obase = (size_t)j * (j + 1) / 2;
+                                const int obase = j * (j + 1) / 2;
                                 if (wa && na <= j) Tp[obase + na] = oa;
                                 if (wb && nb <= j) Tp[obase + nb] = ob;
                             }
@@ -401,14 +414,19 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     falg += 2.0 * nn * nn + 2.0 * nn * (nn - iq) + (double)iq * iq;
                     // ---- d = J' n+ : rows 0 .. kip in four bands, a lane's two columns ------
                     {
-                        const int band = (kip + BW) / BW, r0 = wave * band, r1 = min(r0 + band, kip + 1);
-                        const double *ja = J + (size_t)c0 * ldj, *jb = J + (size_t)c1 * ldj;
+                        // bands of a multiple of four rows; rows past kip meet zc's zero padding
+                        const int band = 4 * ((kip + 4 * BW) / (4 * BW)), r0 = wave * band;
+                        const int r1 = min(r0 + band, (kip + 4) & ~3);
+                        const double *ja = J + c0 * ldj, *jb = J + c1 * ldj;
+                        const double *zk = zc + kip;
                         double a0 = 0.0, a1 = 0.0;
-#pragma unroll 4
-                        for (int r = r0; r < r1; r++) {
-                            const double nr = zc[kip - r];
-                            a0 = fma(ja[r], nr, a0);
-                            a1 = fma(jb[r], nr, a1);
+                        for (int r = r0; r < r1; r += 4) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const double nr = zk[-(r + e)];
+                                a0 = fma(ja[r + e], nr, a0);
+                                a1 = fma(jb[r + e], nr, a1);
+                            }
                         }
                         dpart[wave * PSTR + i0] = sgn * a0;
                         dpart[wave * PSTR + i1] = sgn * a1;
@@ -422,6 +440,8 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     d1 = v1 ? d1 : 0.0;
                     dsv[i0] = d0;
                     dsv[i1] = d1;
+                    d1s[i0] = i0 < iq ? d0 : 0.0;
+                    d1s[i1] = i1 < iq ? d1 : 0.0;
                     // last column of the free part with a nonzero d (beyond it z gets nothing)
                     int jt;
                     {
@@ -431,34 +451,40 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     }
                     wsync();
                     // ---- z = J2 d2 over columns iq .. jt in four segments; r = T d1 likewise ----
-                    const int seg = (jt - iq + 1 + BW - 1) / BW;
-                    const int slo = iq + wave * seg, shi = min(slo + seg, jt + 1);
+                    // segments of a multiple of four columns; d is zero past jt
+                    const int seg = 4 * ((jt - iq + 1 + 4 * BW - 1) / (4 * BW));
+                    const int slo = iq + wave * seg, shi = min(slo + seg, iq + ((jt - iq + 4) & ~3));
                     double jb0 = 0.0, jb1 = 0.0; // column slo - 1, kept for the update of column slo
                     {
                         double a0 = 0.0, a1 = 0.0;
                         const double *j0p = J + c0, *j1p = J + c1;
-#pragma unroll 4
-                        for (int j = slo; j < shi; j++) {
-                            const double dj = dsv[j];
-                            a0 = fma(j0p[(size_t)j * ldj], dj, a0);
-                            a1 = fma(j1p[(size_t)j * ldj], dj, a1);
+                        for (int j = slo; j < shi; j += 4) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const double dj = dsv[j + e];
+                                a0 = fma(j0p[(j + e) * ldj], dj, a0);
+                                a1 = fma(j1p[(j + e) * ldj], dj, a1);
+                            }
                         }
                         if (slo > iq && slo < shi) {
-                            jb0 = j0p[(size_t)(slo - 1) * ldj];
-                            jb1 = j1p[(size_t)(slo - 1) * ldj];
+                            jb0 = j0p[(slo - 1) * ldj];
+                            jb1 = j1p[(slo - 1) * ldj];
                         }
                         zpart[wave * PSTR + i0] = a0;
                         zpart[wave * PSTR + i1] = a1;
                         // r_i = sum_k T(i, k) d_k, k in this wave's quarter of [0, iq)
-                        const int tseg = (iq + BW - 1) / BW, k0 = wave * tseg, k1 = min(k0 + tseg, iq);
+                        const int tseg = 4 * ((iq + 4 * BW - 1) / (4 * BW)), k0 = wave * tseg;
+                        const int k1 = min(k0 + tseg, (iq + 3) & ~3);
                         double b0 = 0.0, b1 = 0.0;
-#pragma unroll 4
-                        for (int k = k0; k < k1; k++) {
-                            const size_t base = (size_t)k * (k + 1) / 2;
-                            const double dk = dsv[k];
-                            const double t0 = Tp[base + min(i0, k)], t1 = Tp[base + min(i1, k)];
-                            b0 = fma(i0 <= k ? t0 : 0.0, dk, b0);
-                            b1 = fma(i1 <= k ? t1 : 0.0, dk, b1);
+                        for (int k = k0; k < k1; k += 4) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int kk = k + e, base = kk * (kk + 1) / 2;
+                                const double dk = d1s[kk];
+                                const double t0 = Tp[base + min(i0, kk)], t1 = Tp[base + min(i1, kk)];
+                                b0 = fma(i0 <= kk ? t0 : 0.0, dk, b0);
+                                b1 = fma(i1 <= kk ? t1 : 0.0, dk, b1);
+                            }
                         }
                         rpart[wave * PSTR + i0] = b0;
                         rpart[wave * PSTR + i1] = b1;
@@ -564,19 +590,38 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                             }
                             double *j0p = J + c0, *j1p = J + c1;
                             if (slo < shi) {
-                                double cur0 = j0p[(size_t)(shi - 1) * ldj], cur1 = j1p[(size_t)(shi - 1) * ldj];
-                                for (int j = shi - 1; j >= slo; j--) {
-                                    const bool bottom = j == slo;
-                                    const double prev0 = bottom ? jb0 : j0p[(size_t)(j - 1) * ldj];
-                                    const double prev1 = bottom ? jb1 : j1p[(size_t)(j - 1) * ldj];
-                                    const double dj = dsv[j], aj = ca[j], bj = cb[j];
-                                    P0 = fma(cur0, dj, P0);
-                                    P1 = fma(cur1, dj, P1);
-                                    const double o0 = fma(aj, P0, bj * prev0), o1 = fma(aj, P1, bj * prev1);
-                                    if (v0) j0p[(size_t)j * ldj] = o0;
-                                    if (v1) j1p[(size_t)j * ldj] = o1;
-                                    cur0 = prev0;
-                                    cur1 = prev1;
+                                double cur0 = j0p[(shi - 1) * ldj], cur1 = j1p[(shi - 1) * ldj];
+                                for (int jtop = shi - 1; jtop >= slo; jtop -= 4) {
+                                    // columns jtop .. jtop - 3 (the segment is a multiple of four long);
+                                    // everything the group reads is loaded before its first store, or each
+                                    // column would wait for the store of the one before
+                                    double p0v[4], p1v[4], dv[4], av[4], bv4[4];
+#pragma unroll
+                                    for (int e = 0; e < 4; e++) {
+                                        const int j = jtop - e;
+                                        p0v[e] = j0p[(j - 1) * ldj];
+                                        p1v[e] = j1p[(j - 1) * ldj];
+                                        dv[e] = dsv[j];
+                                        av[e] = ca[j];
+                                        bv4[e] = cb[j];
+                                    }
+                                    if (jtop - 3 == slo) { // the column below the segment was read before the barrier
+                                        p0v[3] = jb0;
+                                        p1v[3] = jb1;
+                                    }
+#pragma unroll
+                                    for (int e = 0; e < 4; e++) {
+                                        const int j = jtop - e;
+                                        P0 = fma(cur0, dv[e], P0);
+                                        P1 = fma(cur1, dv[e], P1);
+                                        const double o0 = fma(av[e], P0, bv4[e] * p0v[e]), o1 = fma(av[e], P1, bv4[e] * p1v[e]);
+                                        if (j <= jt) { // columns past jt keep what they hold
+                                            if (v0) j0p[j * ldj] = o0;
+                                            if (v1) j1p[j * ldj] = o1;
+                                        }
+                                        cur0 = p0v[e];
+                                        cur1 = p1v[e];
+                                    }
                                 }
                             }
                         }
@@ -609,7 +654,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                         R_norm = fmax(R_norm, rho);
                         // new column of T = [-r; 1] / rho  (wave 0 stores it)
                         if (wave == 0) {
-                            const size_t base = (size_t)iq * (iq + 1) / 2;
+                            const int base = iq * (iq + 1) / 2;
                             if (i0 < iq) Tp[base + i0] = -r0v * irho;
                             if (i1 < iq) Tp[base + i1] = -r1v * irho;
                             if (i0 == iq) Tp[base + i0] = irho;
@@ -699,7 +744,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
             // computeCOMtrajectory (MPCPlanner.cpp:196-209): Sx x0 + Su jerk with the Toeplitz columns
             for (int k = tid; k < N; k += BT) {
                 const size_t o = (size_t)inst * N + k;
-                const double *pr = ws.xpx + (size_t)k * 3, *vr = ws.xvx + (size_t)k * 3;
+                const double *pr = ws.xpx + k * 3, *vr = ws.xvx + k * 3;
                 double cx = pr[0] * w4[0] + pr[1] * w4[1] + pr[2] * w4[2];
                 double vx = vr[0] * w4[0] + vr[1] * w4[1] + vr[2] * w4[2];
                 for (int j = 0; j <= k; j++) {
@@ -720,7 +765,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
 
 size_t box_dense_lds_bytes(const DevSetup &sd) {
     const size_t n = sd.N;
-    const size_t doubles = n * (n | 1) + n * (n + 1) / 2 + PSTR + 8 * PSTR + 1 + 4 * BW * PSTR;
+    const size_t doubles = n * (n | 1) + n * (n + 1) / 2 + PSTR + 10 * PSTR + 4 * BW * PSTR;
     return doubles * 8;
 }
 

@@ -16,7 +16,11 @@ import sys
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
-    out = {"source": os.path.basename(src.rstrip("/")), "kernels": {}}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mpc_amd.provenance import kernel_source_sha
+    # the fingerprint of the kernel sources this profile was taken from (run this script on the
+    # same tree that was profiled); bench.py only uses counter-derived figures of matching code
+    out = {"source": os.path.basename(src.rstrip("/")), "kernel_source_sha": kernel_source_sha(), "kernels": {}}
     for path in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
         for row in csv.DictReader(open(path)):
             name = row["Name"]
