@@ -476,14 +476,25 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                         const int tseg = 4 * ((iq + 4 * BW - 1) / (4 * BW)), k0 = wave * tseg;
                         const int k1 = min(k0 + tseg, (iq + 3) & ~3);
                         double b0 = 0.0, b1 = 0.0;
-                        for (int k = k0; k < k1; k += 4) {
+                        if (iq > HALF) {
+                            for (int k = k0; k < k1; k += 4) {
 #pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                const int kk = k + e, base = kk * (kk + 1) / 2;
-                                const double dk = d1s[kk];
-                                const double t0 = Tp[base + min(i0, kk)], t1 = Tp[base + min(i1, kk)];
-                                b0 = fma(i0 <= kk ? t0 : 0.0, dk, b0);
-                                b1 = fma(i1 <= kk ? t1 : 0.0, dk, b1);
+                                for (int e = 0; e < 4; e++) {
+                                    const int kk = k + e, base = kk * (kk + 1) / 2;
+                                    const double dk = d1s[kk];
+                                    const double t0 = Tp[base + min(i0, kk)], t1 = Tp[base + min(i1, kk)];
+                                    b0 = fma(i0 <= kk ? t0 : 0.0, dk, b0);
+                                    b1 = fma(i1 <= kk ? t1 : 0.0, dk, b1);
+                                }
+                            }
+                        } else { // no working-set position in the lanes' second half yet
+                            for (int k = k0; k < k1; k += 4) {
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const int kk = k + e, base = kk * (kk + 1) / 2;
+                                    const double t0 = Tp[base + min(i0, kk)];
+                                    b0 = fma(i0 <= kk ? t0 : 0.0, d1s[kk], b0);
+                                }
                             }
                         }
                         rpart[wave * PSTR + i0] = b0;
