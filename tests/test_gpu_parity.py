@@ -586,3 +586,111 @@ def test_shapes_beyond_the_dense_kernels_lds_are_rejected_at_create(P):
         P.BatchedPlanner(512, formulation=P.COUPLED_VEL, weight_R=0.01, number_of_steps=255)
     P.BatchedPlanner(512, formulation=P.COUPLED_VEL, weight_R=0.01, number_of_steps=16)  # fits
     P.BatchedPlanner(300, formulation=P.BOX_SLACK, weight_R=1.0, weight_Qs=10.0)         # fits
+
+
+def test_symmetric_scene_with_exact_ties_vs_oracle(P, oracle):
+    """The reference driver's own scene (testPlannerXYconstraintCoupled.cpp:80-88: feet exactly at
+    y = +-1, CoM on the axis, no lateral speed) is mirror-symmetric, so left and right polygon
+    edges evaluate to exactly equal values: the lowest-row tie-break of step 2
+    (eiquadprog.hpp:280-287) decides.  No jitter here; velocity form, where constraints bind."""
+    B, N, steps = 16, 200, 20
+    x0 = np.zeros((B, 3))
+    y0 = np.zeros((B, 3))
+    speed = np.stack([np.linspace(0.05, 0.2, B), np.zeros(B)], axis=1)
+    feet_x = np.tile([0.1, 0.2, -0.4, -0.3], (B, 1))
+    feet_y = np.tile([1.0, -1.0, 1.0, -1.0], (B, 1))
+    swing0 = np.array([0, 3, 1, 2] * (B // 4), dtype=np.int32)
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
+    o = _np(pl.solve_coupled(x0, y0, speed, feet_x, feet_y, swing0))
+    ref = oracle.coupled_batch(oracle.params(N, R=0.01, Q=1.0, height=0.5, iter_cap=4000), oracle.COUPLED_VEL,
+                               steps, 1000, x0, y0, speed, feet_x, feet_y, swing0, nthreads=16)
+    assert ref["n_active"].min() >= 1
+    _check_coupled(o, ref, B)
+
+
+def test_default_weight_R_per_output_tolerances(P, oracle):
+    """weight_R = 1e-6 is the reference constructor's default (MPCPlanner.cpp:39); cond(G) ~ 1e10
+    there.  Every output still meets the 1e-6 bar against the CPU restatement (measured on an
+    MI355X: CoM 5e-9, ZMP 8e-8, jerk 2e-7, objective 1e-8 relative; status, iteration counts and
+    working sets identical), part of the batch through the dense second stage."""
+    B, N, steps = 32, 200, 20
+    bt = batches.coupled_batch(B)
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=1e-6, weight_Q=1.0, number_of_steps=steps)
+    o = _np(pl.solve_coupled(**bt))
+    ref = oracle.coupled_batch(oracle.params(N, R=1e-6, Q=1.0, height=0.5, iter_cap=4000), oracle.COUPLED_VEL,
+                               steps, 1000, bt["x0"], bt["y0"], bt["speed"], bt["feet_x"], bt["feet_y"],
+                               bt["swing0"], nthreads=16)
+    assert (o["status"] == ref["status"]).all() and (o["iters"] == ref["iters"]).all()
+    worst = {}
+    for k in ("com_x", "com_y", "zmp_x", "zmp_y", "jerk_x", "jerk_y"):
+        worst[k] = max(_rel(o[k][i], ref[k][i]) for i in range(B))
+    worst["cost"] = (np.abs(o["cost"] - ref["cost"]) / np.abs(ref["cost"])).max()
+    print("achieved relative agreement at weight_R = 1e-6:", {k: "%.1e" % v for k, v in worst.items()})
+    for k, v in worst.items():
+        assert v < RTOL, (k, v)
+    assert (ref["n_active"] > 32).any()  # beyond the first stage's capacity
+
+
+def _kkt(G, g0, Cn, ci0, x, act, u):
+    """Residuals of the optimality conditions of min 1/2 x'Gx + g0'x s.t. Cn x + ci0 >= 0 at (x, u on act)."""
+    s = Cn @ x + ci0
+    grad = G @ x + g0 - Cn[act].T @ u
+    # primal feasibility in the solver's own measure: the SUM of violations, which the reference
+    # lets reach m * eps * trace(G) * trace(L^-T) * 100 before it stops (eiquadprog.hpp:267)
+    thr = len(ci0) * np.finfo(float).eps * np.trace(G) * np.sum(1.0 / np.diag(np.linalg.cholesky(G))) * 100.0
+    return dict(stationarity=np.abs(grad).max() / max(1e-300, np.abs(g0).max(), np.abs(G @ x).max()),
+                primal=np.minimum(0.0, s).sum() / thr, dual=min(0.0, u.min()) if len(u) else 0.0,
+                complementarity=np.abs(u * s[act]).max() if len(u) else 0.0)
+
+
+def test_kkt_conditions_from_an_independent_assembly(P, oracle):
+    """Optimality of the GPU's (x, multipliers) checked against G, g0, CI, ci0 assembled in numpy
+    straight from the reference's formulas -- a second restatement, independent of the C++ one:
+    solveQPConstraintCoupledRef (MPCPlanner.cpp:723-760) at full size, and solveQPconstraintSlack
+    (:351-394)."""
+    import zspace_model as Z
+    N, steps, R, Q, Qs = 200, 20, 0.01, 1.0, 1.0   # Qs = 1: constraints bind
+    B = 3
+    bt = batches.coupled_batch(B, first=31000)
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_REF, weight_R=R, weight_Q=Q, weight_Qs=Qs, number_of_steps=steps)
+    o = _np(pl.solve_coupled(**bt))
+    su = Z.Setup(N, 0.1, 9.81, 0.5, R, Q, Qs, variant=2)
+    G1 = R * np.eye(N) + su.Xvu.T @ (Q * su.Xvu) + Qs * su.Zu.T @ su.Zu
+    G = np.zeros((2 * N, 2 * N))
+    G[:N, :N] = G1
+    G[N:, N:] = G1
+    assert o["n_active"].max() > 0
+    for i in range(B):
+        st = oracle.compute_steps(N, steps, bt["speed"][i], bt["feet_x"][i], bt["feet_y"][i], bt["swing0"][i])
+        cx, cy = oracle.centroid(st["fx"], st["fy"], st["swing"])
+        A, b = st["A"], st["b"]
+        g0 = np.concatenate([
+            su.Xvu.T @ (Q * (su.Xvx @ bt["x0"][i] - bt["speed"][i, 0])) + Qs * su.Zu.T @ (su.Zx @ bt["x0"][i] - cx),
+            su.Xvu.T @ (Q * (su.Xvx @ bt["y0"][i] - bt["speed"][i, 1])) + Qs * su.Zu.T @ (su.Zx @ bt["y0"][i] - cy)])
+        Cn = np.hstack([A[:, :N] @ su.Zu, A[:, N:] @ su.Zu])
+        ci0 = b + A[:, :N] @ (su.Zx @ bt["x0"][i]) + A[:, N:] @ (su.Zx @ bt["y0"][i])
+        na = o["n_active"][i]
+        k = _kkt(G, g0, Cn, ci0, np.concatenate([o["jerk_x"][i], o["jerk_y"][i]]), o["active_idx"][i, :na],
+                 o["multipliers"][i, :na])
+        assert k["stationarity"] < 1e-7 and k["primal"] > -1.0 and k["dual"] > -1e-9 and k["complementarity"] < 1e-6, k
+        f = 0.5 * np.concatenate([o["jerk_x"][i], o["jerk_y"][i]]) @ G @ np.concatenate([o["jerk_x"][i], o["jerk_y"][i]]) \
+            + g0 @ np.concatenate([o["jerk_x"][i], o["jerk_y"][i]])
+        assert abs(f - o["cost"][i]) < 1e-6 * abs(f)
+    # slack form: x = [jerk; slack per bound], G = diag(R I, Qs I), g0 = [0; 1000 Qs]
+    Ns, Rs, Qss = 60, 0.5, 10.0
+    bb = batches.decoupled_batch(4, N=Ns, steps=6)
+    ps = P.BatchedPlanner(Ns, formulation=P.BOX_SLACK, weight_R=Rs, weight_Qs=Qss, active_stride=4 * Ns)
+    os_ = _np(ps.solve_box(bb["y0"], bb["ymin"], bb["ymax"], outputs=P.SLACK_OUTPUTS))
+    s2 = Z.Setup(Ns, 0.1, 9.81, 0.5, Rs, box=True)
+    Gs = np.diag(np.concatenate([np.full(Ns, Rs), np.full(2 * Ns, Qss)]))
+    g0s = np.concatenate([np.zeros(Ns), np.full(2 * Ns, 1000.0 * Qss)])
+    I = np.eye(Ns)
+    Z0 = np.zeros((Ns, Ns))
+    Cn = np.block([[s2.Zu, I, Z0], [-s2.Zu, Z0, I], [Z0, -I, Z0], [Z0, Z0, -I]])
+    for i in range(4):
+        zf = s2.Zx @ bb["y0"][i]
+        ci0 = np.concatenate([zf - bb["ymin"][i], bb["ymax"][i] - zf, np.zeros(2 * Ns)])
+        na = os_["n_active"][i]
+        k = _kkt(Gs, g0s, Cn, ci0, np.concatenate([os_["jerk_x"][i], os_["slacks"][i]]), os_["active_idx"][i, :na],
+                 os_["multipliers"][i, :na])
+        assert k["stationarity"] < 1e-9 and k["primal"] > -1.0 and k["dual"] > -1e-9 and k["complementarity"] < 1e-6, k
