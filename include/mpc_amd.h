@@ -113,6 +113,12 @@ typedef struct {
      * (2*number_of_steps + 1 phases: four-stance, three-stance, ..., trailing knots);
      * NULL = centroid of the stance feet (computeCentroid).  Required with rows_pqr.       */
     const double  *zref_phase; /* [B][nphase][2] or NULL                                 */
+    /* Optional CoM height per instance: the `actual_height` argument the reference takes on
+     * every solve call (MPCPlanner.cpp:493-502,516).  NULL = mpcb_params.height for all.
+     * Available for COUPLED_JERK and COUPLED_VEL (their Hessian does not depend on the
+     * height, so one handle serves every height); COUPLED_REF keeps the per-handle height.
+     * The first call that passes heights builds a few more tables (one-off, ~0.1 s).      */
+    const double  *height;     /* [B] or NULL                                             */
 } mpcb_coupled_inputs;
 
 /* Outputs.  Any pointer may be NULL (that output is skipped). */
@@ -213,11 +219,12 @@ int  mpcb_replan_sweep_device(mpcb_handle h, int32_t B, int32_t n_stages, int32_
  * With a BOX_SLACK handle the same call is solveQPconstraintSlack: 3N variables (jerk and
  * one slack per bound), 4N rows (active_idx >= 2N: the sign constraint of slack
  * active_idx - 2N); the working set holds about 2N rows, so give active_stride >= 4N to
- * receive all of it; min_margin is the distance of the ZMP to the nearer bound. */
+ * receive all of it; min_margin is the distance of the ZMP to the nearer bound.
+ * height [B]: actual_height per instance, or NULL for mpcb_params.height (both handle kinds). */
 int  mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const double *zmin,
-                           const double *zmax, const mpcb_outputs *out, void *stream);
+                           const double *zmax, const double *height, const mpcb_outputs *out, void *stream);
 int  mpcb_solve_box(mpcb_handle h, int32_t B, const double *x0, const double *zmin,
-                    const double *zmax, const mpcb_outputs *out);
+                    const double *zmax, const double *height, const mpcb_outputs *out);
 
 /* Unconstrained ZMP tracking: solveQP (MPCPlanner.cpp:223-237) for B instances.
  * x0 [B][3], zmp_ref [B][N].  Outputs: jerk_x, zmp_x, com_x, com_xd (status = OK). */

@@ -345,7 +345,7 @@ class MPCPlanner {
         mpcb_handle h = handle(MPCB_BOX_1D, actual_height, 1000, 1);
         jerk.assign(horizon_size_, 0.0);
         mpcb_outputs o = outputs(jerk.data(), nullptr);
-        check(mpcb_solve_box(h, 1, x0.data(), zmpLim.min.data(), zmpLim.max.data(), &o));
+        check(mpcb_solve_box(h, 1, x0.data(), zmpLim.min.data(), zmpLim.max.data(), &actual_height, &o));
         finish(o);
     }
     // :303-424: one slack variable per bound (weight_Qs), kept in `slacks` like the
@@ -363,7 +363,7 @@ class MPCPlanner {
         o.active_idx = last_active_.data();
         o.active_stride = (int)last_active_.size();
         o.slacks = slacks.data();
-        check(mpcb_solve_box(h, 1, x0.data(), zmpLim.min.data(), zmpLim.max.data(), &o));
+        check(mpcb_solve_box(h, 1, x0.data(), zmpLim.min.data(), zmpLim.max.data(), &actual_height, &o));
         finish(o);
     }
     VectorXd slacks;
@@ -578,6 +578,8 @@ class MPCPlanner {
     int number_of_steps_ = 0;
     LegDataMap<footState> last_feet_;
     std::map<Key, mpcb_handle> handles_;
+    std::map<Key, unsigned long long> last_use_;
+    unsigned long long use_clock_ = 0;
     double last_cost_ = 0.0;
     int last_status_ = 0, last_nactive_ = 0, last_iters_ = 0;
     std::vector<int> last_active_;
@@ -589,10 +591,33 @@ class MPCPlanner {
     static void check(int rc) {
         if (rc < 0) throw std::runtime_error(std::string("mpc_amd: ") + mpcb_last_error());
     }
+    // One library handle per (formulation, weights, window, steps, horizon).  The height is passed
+    // with every call (as the reference does) wherever the handle's tables do not depend on it;
+    // only the ZMP-reference and the unconstrained form need a handle per height.  The hip
+    // offsets are not part of the key: this class always hands the library finished polygon
+    // rows, so the library never runs computeSteps with them.  At most kMaxHandles handles are
+    // kept; the least recently used one is destroyed when another is needed.
+    static constexpr size_t kMaxHandles = 8;
+    static bool height_in_tables(int formulation) {
+        return formulation == MPCB_COUPLED_REF || formulation == MPCB_UNCONSTRAINED;
+    }
     mpcb_handle handle(int formulation, double height, int rw, int steps) {
-        const Key key(formulation, height, weight_R_, weight_Q_, weight_Qs_, rw, steps, horizon_size_);
+        const Key key(formulation, height_in_tables(formulation) ? height : 0.0, weight_R_, weight_Q_, weight_Qs_,
+                      rw, steps, horizon_size_);
         auto it = handles_.find(key);
-        if (it != handles_.end()) return it->second;
+        if (it != handles_.end()) {
+            last_use_[key] = ++use_clock_;
+            return it->second;
+        }
+        if (handles_.size() >= kMaxHandles) {
+            auto oldest = handles_.begin();
+            for (auto jt = handles_.begin(); jt != handles_.end(); ++jt)
+                if (last_use_[jt->first] < last_use_[oldest->first]) oldest = jt;
+            mpcb_destroy(oldest->second);
+            last_use_.erase(oldest->first);
+            handles_.erase(oldest);
+        }
+        last_use_[key] = ++use_clock_;
         mpcb_params p = {};
         p.horizon = horizon_size_;
         p.formulation = formulation;
@@ -676,6 +701,7 @@ class MPCPlanner {
         in.speed = speed.data();
         in.rows_pqr = rows.data();
         in.zref_phase = zrefx ? zph.data() : nullptr;
+        in.height = height_in_tables(formulation) ? nullptr : &height;
         mpcb_outputs o = outputs(jerk_x.data(), jerk_y.data());
         check(mpcb_solve_coupled(h, 1, &in, &o));
         finish(o);
@@ -732,6 +758,7 @@ class MPCPlanner {
         in.speed = speed.data();
         in.rows_pqr = rows.data();
         in.zref_phase = zrefx ? zph.data() : nullptr;
+        in.height = height_in_tables(formulation) ? nullptr : &height;
         mpcb_outputs o = outputs(jerk_x.data(), jerk_y.data());
         last_active_.assign(4 * N, -1);
         o.active_idx = last_active_.data();

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
     const bool v0 = i0 < n, v1 = i1 < n;
     const int c0 = v0 ? i0 : n - 1, c1 = v1 ? i1 : n - 1;
 
-    for (int k = tid; k < 2 * PSTR; k += BT) zc[k - PSTR] = (k >= PSTR && k - PSTR < N) ? ws.zu_col[k - PSTR] : 0.0;
+    for (int k = tid; k < PSTR; k += BT) zc[k - PSTR] = 0.0;
     for (int k = tid; k < PSTR; k += BT) xs[k] = 0.0; // entries >= n stay zero
     const int count = *ws.count;
     for (int entry = blockIdx.x; entry < count; entry += gridDim.x) {
@@ -113,6 +113,11 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
 #endif
         __syncthreads();
         // ---- inputs --------------------------------------------------------------
+        // Cz = Cx - c Ca (MPCPlanner.cpp:58-63): with a height per instance the Toeplitz column of
+        // Zu and the third column of Zx are shifted by c = height / gravity
+        const bool hv = in.height != nullptr;
+        const double ch = hv ? in.height[inst] * sd.inv_gravity : 0.0;
+        for (int k = tid; k < PSTR; k += BT) zc[k] = k < N ? (hv ? ws.xp_col[k] - ch * sd.Ts : ws.zu_col[k]) : 0.0;
         double w4[4];
         {
             const double *px = in.x0 + (size_t)inst * 3;
@@ -125,9 +130,9 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
         const double lo1 = v1 ? in.zmin[(size_t)inst * N + i1] : -DINF, hi1 = v1 ? in.zmax[(size_t)inst * N + i1] : DINF;
         double zf0, zf1; // Zx x0 at the lane's knots
         {
-            const double *a = ws.zx + c0 * 3, *b = ws.zx + c1 * 3;
-            zf0 = a[0] * w4[0] + a[1] * w4[1] + a[2] * w4[2];
-            zf1 = b[0] * w4[0] + b[1] * w4[1] + b[2] * w4[2];
+            const double *a = (hv ? ws.xpx : ws.zx) + c0 * 3, *b = (hv ? ws.xpx : ws.zx) + c1 * 3;
+            zf0 = a[0] * w4[0] + a[1] * w4[1] + (a[2] - ch) * w4[2];
+            zf1 = b[0] * w4[0] + b[1] * w4[1] + (b[2] - ch) * w4[2];
         }
         // The unrolled sweeps run a few rows / columns past the end of their range with zero
         // coefficients; what they read there (J's padding row, the start of T) must be finite.

@@ -247,6 +247,7 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
     ds.psi_thr = (double)hs.m * 2.220446049250313e-16 * hs.c1 * hs.c2 * 100.0;
     ds.traceG1 = hs.traceG1;
     ds.Ts = params->Ts;
+    ds.inv_gravity = 1.0 / params->gravity;
     std::memcpy(ds.hip, params->hip_offsets, sizeof(ds.hip));
     if ((rc = upload_to(h, hs.S, &ds.S)) || (rc = upload_to(h, hs.Wt, &ds.Wt)) ||
         (rc = upload_to(h, hs.Sc, &ds.Sc)) || (rc = upload_to(h, hs.Sv, &ds.Sv)) ||
@@ -337,6 +338,23 @@ int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
         HIP_TRY(hipMalloc((void **)&h->ws.R, (size_t)want * n * n * sizeof(double)));
         h->dense_slots = want;
     }
+    return 0;
+}
+
+// Builds and uploads the height-free response tables the first time a batch brings its own
+// heights (one-off host work and allocations, like mpcb_create's).
+int ensure_height_tables(mpcb_handle h) {
+    if (h->ds.Spp) return 0;
+    const char *err = "";
+    int rc = mpcb::build_height_tables(h->params, h->hs, &err);
+    if (rc) return fail(rc, err);
+    mpcb::DevSetup &ds = h->ds;
+    const mpcb::HostSetup &hs = h->hs;
+    if ((rc = upload_to(h, hs.Sps, &ds.Sps)) || (rc = upload_to(h, hs.Saa, &ds.Saa)) ||
+        (rc = upload_to(h, hs.Wtp, &ds.Wtp)) || (rc = upload_to(h, hs.Wta, &ds.Wta)) ||
+        (rc = upload_to(h, hs.Kzp, &ds.Kzp)) || (rc = upload_to(h, hs.Kza, &ds.Kza)) ||
+        (rc = upload_to(h, hs.Spp, &ds.Spp)))
+        return rc;
     return 0;
 }
 
@@ -449,6 +467,9 @@ static int coupled_arguments(mpcb_handle h, int32_t B, const mpcb_coupled_inputs
     di.com0 = in->com0;
     di.rows_pqr = in->rows_pqr;
     di.zref_phase = in->zref_phase;
+    di.height = in->height;
+    if (in->height && form == MPCB_COUPLED_REF)
+        return fail(MPCB_E_ARG, "COUPLED_REF takes its height from mpcb_params: its Hessian depends on it");
     return 0;
 }
 
@@ -458,6 +479,7 @@ int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_input
     int rc = coupled_arguments(h, B, in, out, di);
     if (rc || B == 0) return rc;
     DeviceGuard guard(h->params.device);
+    if (di.height && (rc = ensure_height_tables(h))) return rc;
     return solve_two_stage(h, di, *out, B, (hipStream_t)stream);
 }
 
@@ -474,6 +496,9 @@ int mpcb_solve_coupled_device_noalloc(mpcb_handle h, int32_t B, const mpcb_coupl
                                     " variables per QP (horizon 200)");
     if (h->params.device >= MAX_DEVICES || !g_scratch[h->params.device])
         return fail(MPCB_E_ARG, "mpcb_solve_coupled_device_noalloc: no scratch on this device");
+    if (di.height && !h->ds.Spp)
+        return fail(MPCB_E_ARG, "mpcb_solve_coupled_device_noalloc: the tables for per-instance heights are built (and "
+                                "allocated) by the first mpcb_solve_coupled[_device] call that passes heights");
     DeviceGuard guard(h->params.device);
     // the handle's tables with this device's static scratch in place of the allocated workspace
     unsigned char *ptr = g_scratch[h->params.device];
@@ -511,7 +536,7 @@ int mpcb_solve_coupled_multi(const mpcb_handle *handles, int32_t n_handles, int3
         mpcb_outputs so = *out;
 #define IN_(field, w) if (si.field) si.field += first * (w);
         IN_(x0, 3) IN_(y0, 3) IN_(speed, 2) IN_(feet_x, 4) IN_(feet_y, 4) IN_(swing0, 1) IN_(com0, 2)
-        IN_(rows_pqr, m * 3) IN_(zref_phase, P * 2)
+        IN_(rows_pqr, m * 3) IN_(zref_phase, P * 2) IN_(height, 1)
 #undef IN_
 #define OUT_(field, w) if (so.field) so.field += first * (w);
         OUT_(jerk_x, N) OUT_(jerk_y, N) OUT_(com_x, N) OUT_(com_y, N) OUT_(com_xd, N) OUT_(com_yd, N)
@@ -597,7 +622,7 @@ int mpcb_replan_sweep_device(mpcb_handle h, int32_t B, int32_t n_stages, int32_t
 }
 
 int mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const double *zmin,
-                          const double *zmax, const mpcb_outputs *out, void *stream) {
+                          const double *zmax, const double *height, const mpcb_outputs *out, void *stream) {
     if (!h || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
     if (B == 0) return 0;
     if (!x0 || !zmin || !zmax) return fail(MPCB_E_ARG, "null input array");
@@ -611,6 +636,11 @@ int mpcb_solve_box_device(mpcb_handle h, int32_t B, const double *x0, const doub
     di.x0 = x0;
     di.zmin = zmin;
     di.zmax = zmax;
+    di.height = height;
+    if (height && h->params.formulation == MPCB_BOX_1D) {
+        int rc = ensure_height_tables(h);
+        if (rc) return rc;
+    }
     return solve_two_stage(h, di, *out, B, (hipStream_t)stream);
 }
 
@@ -660,7 +690,8 @@ int mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, 
             (rc = st.in(in->feet_y, b * 4, &di.feet_y)) || (rc = st.in(in->swing0, b, &di.swing0)) ||
             (rc = st.in(in->com0, b * 2, &di.com0)) ||
             (rc = st.in(in->rows_pqr, b * (size_t)h->hs.m * 3, &di.rows_pqr)) ||
-            (rc = st.in(in->zref_phase, b * (size_t)h->hs.nphase * 2, &di.zref_phase)))
+            (rc = st.in(in->zref_phase, b * (size_t)h->hs.nphase * 2, &di.zref_phase)) ||
+            (rc = st.in(in->height, b, &di.height)))
             return rc;
         return stage_outputs(st, *out, dout, b, N);
     };
@@ -671,21 +702,22 @@ int mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, 
 }
 
 int mpcb_solve_box(mpcb_handle h, int32_t B, const double *x0, const double *zmin, const double *zmax,
-                   const mpcb_outputs *out) {
+                   const double *height, const mpcb_outputs *out) {
     if (!h || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
     DeviceGuard guard(h->params.device);
     Staging st(h);
-    const double *dx0, *dmin, *dmax;
+    const double *dx0, *dmin, *dmax, *dheight;
     int rc;
     const size_t b = (size_t)B, N = (size_t)h->hs.N;
     mpcb_outputs dout;
     auto stage = [&]() -> int {
-        if ((rc = st.in(x0, b * 3, &dx0)) || (rc = st.in(zmin, b * N, &dmin)) || (rc = st.in(zmax, b * N, &dmax)))
+        if ((rc = st.in(x0, b * 3, &dx0)) || (rc = st.in(zmin, b * N, &dmin)) || (rc = st.in(zmax, b * N, &dmax)) ||
+            (rc = st.in(height, b, &dheight)))
             return rc;
         return stage_outputs(st, *out, dout, b, N);
     };
     if ((rc = stage()) || (rc = st.commit()) || (rc = stage())) return rc;
-    if ((rc = mpcb_solve_box_device(h, B, dx0, dmin, dmax, &dout, h->own_stream))) return rc;
+    if ((rc = mpcb_solve_box_device(h, B, dx0, dmin, dmax, dheight, &dout, h->own_stream))) return rc;
     if ((rc = fetch_outputs(*out, dout, b, N, h->own_stream))) return rc;
     return count_not_ok(out->status, B);
 }

@@ -145,10 +145,21 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
         else return (size_t)k * n + i;
     };
 
-    for (int k = tid; k < N; k += T) zc[k] = ws.zu_col[k];
     const int count = *ws.count;
     for (int entry = blockIdx.x; entry < count; entry += gridDim.x) {
         const int inst = ws.list[entry];
+        // Cz = Cx - c Ca (MPCPlanner.cpp:58-63): with a height per instance the Toeplitz column of
+        // Zu and the third column of Zx are shifted by c = height / gravity
+        const bool hv = in.height != nullptr;
+        const double ch = hv ? in.height[inst] * sd.inv_gravity : 0.0;
+        __syncthreads();
+        for (int k = tid; k < N; k += T) zc[k] = hv ? ws.xp_col[k] - ch * sd.Ts : ws.zu_col[k];
+        auto zx_row = [&](int k, double &a, double &b, double &c) {
+            const double *zr = (hv ? ws.xpx : ws.zx) + (size_t)k * 3;
+            a = zr[0];
+            b = zr[1];
+            c = hv ? zr[2] - ch : zr[2];
+        };
 #ifdef MPCB_STAMPS
         long long stamp_acc[16] = {0};
         long long stamp_t = __builtin_amdgcn_s_memtime();
@@ -234,9 +245,10 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             for (int k = lane; k < N; k += 64) {
                 double ax = 0.0, ay = 0.0;
                 if (wave == 0) {
-                    const double *zr = ws.zx + (size_t)k * 3;
-                    ax = zr[0] * wx[0] + zr[1] * wx[1] + zr[2] * wx[2];
-                    ay = zr[0] * wy[0] + zr[1] * wy[1] + zr[2] * wy[2];
+                    double z0, z1, z2;
+                    zx_row(k, z0, z1, z2);
+                    ax = z0 * wx[0] + z1 * wx[1] + z2 * wx[2];
+                    ay = z0 * wy[0] + z1 * wy[1] + z2 * wy[2];
                 }
                 const int j1 = min(k, j0 + band - 1);
 #pragma unroll 8
@@ -269,9 +281,10 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                 }
                 ax = wave_sum(ax);
                 if constexpr (POLY) ay = wave_sum(ay);
-                const double *zr = ws.zx + (size_t)k * 3;
-                ax += zr[0] * wx[0] + zr[1] * wx[1] + zr[2] * wx[2];
-                ay += zr[0] * wy[0] + zr[1] * wy[1] + zr[2] * wy[2];
+                double z0, z1, z2;
+                zx_row(k, z0, z1, z2);
+                ax += z0 * wx[0] + z1 * wx[1] + z2 * wx[2];
+                ay += z0 * wy[0] + z1 * wy[1] + z2 * wy[2];
                 if (lane == 0) s[i] = row_value(i, k, ax, ay);
             }
             __syncthreads();

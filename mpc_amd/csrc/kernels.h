@@ -24,6 +24,10 @@ struct DevSetup {
     // knots of one phase, [nphase][N], weight Qs folded in; cost terms F2 [4][nphase],
     // F3 [nphase][nphase]
     const double *Sp, *Wp, *F2, *F3;
+    // per-instance heights (else NULL): S = Spp - c Sps + c^2 Saa, W^T = Wtp - c Wta,
+    // Kz = Kzp - c Kza with c = height / gravity
+    const double *Spp, *Sps, *Saa, *Wtp, *Wta, *Kzp, *Kza;
+    double inv_gravity;
     const int *knot_phase, *knot_row0; // [N]
     double F[16];
     double psi_thr;                   // m * eps * c1 * c2 * 100 (eiquadprog.hpp:267)
@@ -39,6 +43,7 @@ struct DevIn {
     const double *zmin, *zmax;        // BOX_1D
     const double *rows_pqr;           // optional [B][m][3]: caller-built polygon rows
     const double *zref_phase;         // optional [B][nphase][2]: ZMP reference per phase
+    const double *height;             // optional [B]: CoM height per instance (needs the height tables)
 };
 
 // Hand-over from the wave-per-QP kernel to the dense kernel, and the dense kernel's

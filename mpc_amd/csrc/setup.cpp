@@ -371,4 +371,94 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
     return 0;
 }
 
+// Tables for per-instance CoM heights.  With c = height / gravity the ZMP matrices are
+// Zu = Xpu - c Xau and Zx = Xpx - c Xax (MPCPlanner.cpp:58-63: Cz = Cx - c Ca), and for the
+// formulations whose Hessian does not contain Zu (box, coupled jerk-only, coupled velocity)
+// G1^-1 =: H is the same for every height, so
+//     S(c)   = Zu H Zu'  = Spp - c Sps + c^2 Saa
+//     W(c)^T = Zu H      = Wtp - c Wta
+//     Kz(c)  = Zu Kx + Zx = Kzp - c Kza
+// with the seven height-free tables built here (long double, like the others).
+int build_height_tables(const mpcb_params &p, HostSetup &o, const char **err) {
+    const int N = p.horizon, form = p.formulation;
+    if (form != MPCB_BOX_1D && form != MPCB_COUPLED_JERK && form != MPCB_COUPLED_VEL) {
+        *err = "per-instance heights need a formulation whose Hessian does not depend on the height";
+        return MPCB_E_ARG;
+    }
+    const ld Ts = p.Ts;
+    const ld Cx[3] = {1, 0, 0}, Cv[3] = {0, 1, 0}, Ca[3] = {0, 0, 1};
+    Pred Xp = prediction(Cx, Ts, N), Xv = prediction(Cv, Ts, N), Xa = prediction(Ca, Ts, N);
+    LVec G1((size_t)N * N, 0), Gm((size_t)N * 4, 0);
+    for (int i = 0; i < N; i++) G1[(size_t)i * N + i] = p.weight_R;
+    if (form == MPCB_COUPLED_VEL) {
+        LVec w(N);
+        if (p.replanning_window == 1000) {
+            for (int i = 0; i < N; i++) w[i] = p.weight_Q;
+        } else {
+            const ld mean = p.replanning_window, sd = p.replanning_window;
+            for (int i = 0; i < N; i++) {
+                const ld q = ((ld)(i + 1) - mean) / sd;
+                w[i] = expl(-0.5L * q * q) / (sqrtl(2 * (ld)M_PIl) * sd) * (ld)p.weight_Q * (ld)N;
+            }
+        }
+        LVec WX((size_t)N * N, 0), WXx((size_t)N * 4, 0);
+        for (int i = 0; i < N; i++) {
+            for (int k = 0; k <= i; k++) WX[(size_t)i * N + k] = w[i] * Xv.col[i - k];
+            for (int j = 0; j < 3; j++) WXx[(size_t)i * 4 + j] = w[i] * Xv.sx[(size_t)i * 3 + j];
+            WXx[(size_t)i * 4 + 3] = -w[i];
+        }
+        LVec Gv = toepT_mul(Xv.col, WX, N, N);
+        for (size_t i = 0; i < G1.size(); i++) G1[i] += Gv[i];
+        Gm = toepT_mul(Xv.col, WXx, N, 4);
+    }
+    LVec L = G1;
+    if (!cholesky(L, N)) {
+        *err = "condensed Hessian is not positive definite";
+        return MPCB_E_NUMERIC;
+    }
+    // H Xp', H Xa'  (N x N): column k = H * (row k of the Toeplitz matrix)
+    LVec XpT((size_t)N * N, 0), XaT((size_t)N * N, 0);
+    for (int i = 0; i < N; i++)
+        for (int k = i; k < N; k++) {
+            XpT[(size_t)i * N + k] = Xp.col[k - i];
+            XaT[(size_t)i * N + k] = Xa.col[k - i];
+        }
+    LVec Wp = XpT, Wa = XaT;
+    chol_solve(L, Wp, N, N);
+    chol_solve(L, Wa, N, N);
+    LVec Spp = toep_mul(Xp.col, Wp, N, N), Spa = toep_mul(Xp.col, Wa, N, N);
+    LVec Sap = toep_mul(Xa.col, Wp, N, N), Saa = toep_mul(Xa.col, Wa, N, N);
+    LVec Sps((size_t)N * N);
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) {
+            // symmetrised, like S
+            Sps[(size_t)i * N + j] = ((Spa[(size_t)i * N + j] + Sap[(size_t)i * N + j]) +
+                                      (Spa[(size_t)j * N + i] + Sap[(size_t)j * N + i])) / 2;
+        }
+    for (int i = 0; i < N; i++)
+        for (int j = i + 1; j < N; j++) {
+            const ld a = (Spp[(size_t)i * N + j] + Spp[(size_t)j * N + i]) / 2;
+            Spp[(size_t)i * N + j] = Spp[(size_t)j * N + i] = a;
+            const ld b = (Saa[(size_t)i * N + j] + Saa[(size_t)j * N + i]) / 2;
+            Saa[(size_t)i * N + j] = Saa[(size_t)j * N + i] = b;
+        }
+    o.Spp = to_double(Spp);
+    o.Sps = to_double(Sps);
+    o.Saa = to_double(Saa);
+    o.Wtp = to_double_T(Wp, N);
+    o.Wta = to_double_T(Wa, N);
+    LVec Kx = Gm;
+    chol_solve(L, Kx, N, 4);
+    for (ld &v : Kx) v = -v;
+    LVec Kzp = toep_mul(Xp.col, Kx, N, 4), Kza = toep_mul(Xa.col, Kx, N, 4);
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < 3; j++) {
+            Kzp[(size_t)i * 4 + j] += Xp.sx[(size_t)i * 3 + j];
+            Kza[(size_t)i * 4 + j] += Xa.sx[(size_t)i * 3 + j];
+        }
+    o.Kzp = to_double(Kzp);
+    o.Kza = to_double(Kza);
+    return 0;
+}
+
 } // namespace mpcb

@@ -36,9 +36,16 @@ struct HostSetup {
     std::vector<double> xp_col, xpx, xv_col, xvx; // the same for CoM position and velocity
     std::vector<double> J0;                   // L1^-T (N x N, column-major), upper triangular
     std::vector<double> Hneg;                 // -G1^-1 (N x N) row-major
+    // height-free tables for per-instance heights (build_height_tables); empty until asked for
+    std::vector<double> Spp, Sps, Saa, Wtp, Wta;  // N x N
+    std::vector<double> Kzp, Kza;                 // N x 4
 };
 
 // Returns 0 or an MPCB_E_* code; `err` receives a message.
 int build_setup(const mpcb_params &p, HostSetup &out, const char **err);
+
+// Adds the tables that let every instance of a batch have its own CoM height (box, coupled
+// jerk-only and coupled velocity formulations).  Returns 0 or an MPCB_E_* code.
+int build_height_tables(const mpcb_params &p, HostSetup &out, const char **err);
 
 } // namespace mpcb

@@ -166,7 +166,10 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
 
 // ROWS: polygon rows come from the caller (in.rows_pqr, the (p, q, r) of every row of the
 // A, b that computeSteps returned, possibly edited) instead of being built from the feet.
-template <int NPL, bool POLY, bool ROWS>
+// HV: every instance has its own CoM height (in.height): the response tables are combined from
+// their height-free parts as they are read, S = Spp - c Sps + c^2 Saa, W^T = Wtp - c Wta,
+// Kz = Kzp - c Kza with c = height / gravity (three loads per entry instead of one).
+template <int NPL, bool POLY, bool ROWS, bool HV>
 __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
                                                       int *unresolved_list, int *unresolved_count) {
     constexpr int ES = POLY ? 4 : 2;
@@ -243,6 +246,21 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
         }
     }
 
+    double ch = 0.0, ch2 = 0.0; // HV: c and c^2
+    if constexpr (HV) {
+        ch = ufirst(in.height[inst] * sd.inv_gravity);
+        ch2 = ufirst(ch * ch);
+    }
+    // entries of the response tables at a flat offset (row * N + column)
+    auto S_at = [&](size_t off) -> double {
+        if constexpr (HV) return fma(ch2, sd.Saa[off], fma(-ch, sd.Sps[off], sd.Spp[off]));
+        else return sd.S[off];
+    };
+    auto Wt_at = [&](size_t off) -> double {
+        if constexpr (HV) return fma(-ch, sd.Wta[off], sd.Wtp[off]);
+        else return sd.Wt[off];
+    };
+
     // ---- constraint rows ---------------------------------------------------
     int ph[NPL], row0[NPL];
     double lo[NPL], hi[NPL];
@@ -309,20 +327,45 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     // v += sum_a coef_a * M[knot_a, :] over the first n working-set rows.  The loads of a
     // whole group of rows (eight while more than four remain, else four) are in flight
     // together; cx/cy are zero beyond n, so the padding rows add 0.
-    auto accum_group = [&](const double *M, int a0, double *vx, double *vy, auto gtag) {
+    // (wtag: 0 = the ZMP response S, 1 = the jerk response W^T)
+    auto accum_group = [&](auto wtag, int a0, double *vx, double *vy, auto gtag) {
+        constexpr int WH = decltype(wtag)::value;
         constexpr int G = decltype(gtag)::value;
-        const double *row[G];
+        const double *T0 = WH == 0 ? (HV ? sd.Spp : sd.S) : (HV ? sd.Wtp : sd.Wt);
+        size_t off[G];
         double ca[G], cb[G], sv[G][NPL];
 #pragma unroll
         for (int j = 0; j < G; j++) {
-            row[j] = M + (size_t)(ufirst(W.wsKS[a0 + j]) >> 2) * N;
+            off[j] = (size_t)(ufirst(W.wsKS[a0 + j]) >> 2) * N;
             ca[j] = W.cx[a0 + j];
             cb[j] = W.cy[a0 + j];
         }
 #pragma unroll
         for (int j = 0; j < G; j++)
 #pragma unroll
-            for (int c = 0; c < NPL; c++) sv[j][c] = row[j][kc[c]];
+            for (int c = 0; c < NPL; c++) sv[j][c] = T0[off[j] + kc[c]];
+        if constexpr (HV) {
+            const double *T1 = WH == 0 ? sd.Sps : sd.Wta;
+            double s1[G][NPL];
+#pragma unroll
+            for (int j = 0; j < G; j++)
+#pragma unroll
+                for (int c = 0; c < NPL; c++) s1[j][c] = T1[off[j] + kc[c]];
+#pragma unroll
+            for (int j = 0; j < G; j++)
+#pragma unroll
+                for (int c = 0; c < NPL; c++) sv[j][c] = fma(-ch, s1[j][c], sv[j][c]);
+            if constexpr (WH == 0) {
+#pragma unroll
+                for (int j = 0; j < G; j++)
+#pragma unroll
+                    for (int c = 0; c < NPL; c++) s1[j][c] = sd.Saa[off[j] + kc[c]];
+#pragma unroll
+                for (int j = 0; j < G; j++)
+#pragma unroll
+                    for (int c = 0; c < NPL; c++) sv[j][c] = fma(ch2, s1[j][c], sv[j][c]);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < G; j++)
 #pragma unroll
@@ -331,13 +374,15 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 if constexpr (POLY) vy[c] += cb[j] * sv[j][c];
             }
     };
-    auto accum_rows = [&](const double *M, int n, double *vx, double *vy) {
+    auto accum_rows = [&](auto wtag, int n, double *vx, double *vy) {
         int a0 = 0;
-        if constexpr (NPL <= 4) {
-            for (; n - a0 > 4; a0 += 8) accum_group(M, a0, vx, vy, std::integral_constant<int, 8>{});
+        if constexpr (NPL <= 4 && !HV) {
+            for (; n - a0 > 4; a0 += 8) accum_group(wtag, a0, vx, vy, std::integral_constant<int, 8>{});
         }
-        for (; a0 < n; a0 += 4) accum_group(M, a0, vx, vy, std::integral_constant<int, 4>{});
+        for (; a0 < n; a0 += 4) accum_group(wtag, a0, vx, vy, std::integral_constant<int, 4>{});
     };
+    constexpr std::integral_constant<int, 0> TAB_S{};
+    constexpr std::integral_constant<int, 1> TAB_W{};
     // v += sum over phases of (reference of the phase) * Mp[phase, :], eight phases' loads in
     // flight at a time (ZMP-reference formulation)
     auto accum_phases = [&](const double *Mp, double *vx, double *vy) {
@@ -399,7 +444,12 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     double zxu[NPL], zyu[NPL];
 #pragma unroll
     for (int c = 0; c < NPL; c++) {
-        const double *kz = sd.Kz + (size_t)kc[c] * 4;
+        double kz[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            if constexpr (HV) kz[a] = fma(-ch, sd.Kza[(size_t)kc[c] * 4 + a], sd.Kzp[(size_t)kc[c] * 4 + a]);
+            else kz[a] = sd.Kz[(size_t)kc[c] * 4 + a];
+        }
         zxu[c] = kz[0] * wx[0] + kz[1] * wx[1] + kz[2] * wx[2] + kz[3] * wx[3];
         zyu[c] = kz[0] * wy[0] + kz[1] * wy[1] + kz[2] * wy[2] + kz[3] * wy[3];
     }
@@ -457,7 +507,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
             zx[c] = zxu[c];
             zy[c] = zyu[c];
         }
-        accum_rows(sd.S, iq, zx, zy);
+        accum_rows(TAB_S, iq, zx, zy);
         STAMP(1);
         // s(x) for every row (:255-261), fused with the search for the most violated row
         // (step 2, :279-287, first pass: ss = 0).  Row values are not kept: the rare
@@ -599,7 +649,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
             pending = true;
             // n_ip' G^-1 n_ip; the load is consumed after the gather of the first pass has been
             // issued, so that the two memory round trips overlap
-            const double skk = sd.S[(size_t)kip * N + kip];
+            const double skk = S_at((size_t)kip * N + kip);
             // g_a = n_a' G^-1 n_ip depends on the pair (a, ip) only: it is gathered once per
             // candidate, and a drop merely closes the gap (lanes above the dropped position move
             // down by one) instead of paying another round trip to the table
@@ -619,7 +669,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 if (lane < iq) {
                     if (!have_g) {
                         const int ka = W.wsKS[lane] >> 2;
-                        ga = (W.wsP[lane] * pip + W.wsQ[lane] * qip) * sd.S[(size_t)ka * N + kip];
+                        ga = (W.wsP[lane] * pip + W.wsQ[lane] * qip) * S_at((size_t)ka * N + kip);
                     }
                     ua = W.wsU[lane];
                 }
@@ -666,14 +716,13 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                     set_coefs(-ra, iq);
                     double acc = 0.0;
                     double zvx[NPL], zvy[NPL];
-                    const double *wip = sd.Wt + (size_t)kip * N;
 #pragma unroll
                     for (int c = 0; c < NPL; c++) {
-                        const double w = wip[kc[c]];
+                        const double w = Wt_at((size_t)kip * N + kc[c]);
                         zvx[c] = pip * w;
                         zvy[c] = qip * w;
                     }
-                    accum_rows(sd.Wt, iq, zvx, zvy);
+                    accum_rows(TAB_W, iq, zvx, zvy);
 #pragma unroll
                     for (int c = 0; c < NPL; c++)
                         if (kn[c] < N) acc += zvx[c] * zvx[c] + zvy[c] * zvy[c];
@@ -858,7 +907,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
         if constexpr (POLY) {
             if (sd.Wp) accum_phases(sd.Wp, jx, jy);
         }
-        accum_rows(sd.Wt, nresp, jx, jy);
+        accum_rows(TAB_W, nresp, jx, jy);
         store_pair(out.jerk_x, out.jerk_y, jx, jy);
         STAMP(13);
         if (want_com) {
@@ -953,7 +1002,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 zx[c] = zxu[c];
                 zy[c] = zyu[c];
             }
-            accum_rows(sd.S, nresp, zx, zy);
+            accum_rows(TAB_S, nresp, zx, zy);
         }
 #pragma unroll
         for (int c = 0; c < NPL; c++)
@@ -978,7 +1027,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
 #endif
 }
 
-template <int NPL, bool POLY, bool ROWS>
+template <int NPL, bool POLY, bool ROWS, bool HV>
 hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
                       const DenseWs &ws, hipStream_t stream) {
     const size_t per_wave = sizeof(WaveState) + (POLY ? ((size_t)sd.nphase * 14 + 12) * 8 : 0);
@@ -987,7 +1036,7 @@ hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &o
     // several is (iteration counts differ by 2-3x between instances).
     const int wpb = 1;
     size_t shmem = (size_t)wpb * per_wave;
-    auto kfn = zspace_kernel<NPL, POLY, ROWS>;
+    auto kfn = zspace_kernel<NPL, POLY, ROWS, HV>;
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -998,26 +1047,30 @@ hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &o
     return hipGetLastError();
 }
 
+template <bool POLY, bool ROWS, bool HV>
+hipError_t launch_npl(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B, const DenseWs &ws,
+                      hipStream_t stream) {
+    const int npl = (sd.N + 63) / 64;
+    if (npl <= 2) return launch_one<2, POLY, ROWS, HV>(sd, in, out, B, ws, stream);
+    if (npl <= 4) return launch_one<4, POLY, ROWS, HV>(sd, in, out, B, ws, stream);
+    return launch_one<8, POLY, ROWS, HV>(sd, in, out, B, ws, stream);
+}
+
 } // namespace
 
 hipError_t launch_zspace(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
                          const DenseWs &ws, hipStream_t stream) {
     if (B <= 0) return hipSuccess;
     const bool poly = sd.form != MPCB_BOX_1D;
-    const int npl = (sd.N + 63) / 64;
-    if (poly && in.rows_pqr) {
-        if (npl <= 2) return launch_one<2, true, true>(sd, in, out, B, ws, stream);
-        if (npl <= 4) return launch_one<4, true, true>(sd, in, out, B, ws, stream);
-        return launch_one<8, true, true>(sd, in, out, B, ws, stream);
+    if (in.height) {
+        if (!sd.Spp) return hipErrorInvalidValue; // the height tables were not uploaded
+        if (poly && in.rows_pqr) return launch_npl<true, true, true>(sd, in, out, B, ws, stream);
+        if (poly) return launch_npl<true, false, true>(sd, in, out, B, ws, stream);
+        return launch_npl<false, false, true>(sd, in, out, B, ws, stream);
     }
-    if (poly) {
-        if (npl <= 2) return launch_one<2, true, false>(sd, in, out, B, ws, stream);
-        if (npl <= 4) return launch_one<4, true, false>(sd, in, out, B, ws, stream);
-        return launch_one<8, true, false>(sd, in, out, B, ws, stream);
-    }
-    if (npl <= 2) return launch_one<2, false, false>(sd, in, out, B, ws, stream);
-    if (npl <= 4) return launch_one<4, false, false>(sd, in, out, B, ws, stream);
-    return launch_one<8, false, false>(sd, in, out, B, ws, stream);
+    if (poly && in.rows_pqr) return launch_npl<true, true, false>(sd, in, out, B, ws, stream);
+    if (poly) return launch_npl<true, false, false>(sd, in, out, B, ws, stream);
+    return launch_npl<false, false, false>(sd, in, out, B, ws, stream);
 }
 
 } // namespace mpcb

@@ -38,7 +38,7 @@ class Params(C.Structure):
 
 class CoupledInputs(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in
-                ("x0", "y0", "speed", "feet_x", "feet_y", "swing0", "com0", "rows_pqr", "zref_phase")]
+                ("x0", "y0", "speed", "feet_x", "feet_y", "swing0", "com0", "rows_pqr", "zref_phase", "height")]
 
 
 class ReplanState(C.Structure):
@@ -81,7 +81,7 @@ def load_library():
         lib.mpcb_solve_coupled_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                                                  C.POINTER(CoupledInputs), C.POINTER(Outputs)]
         lib.mpcb_solve_box_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
-                                              C.c_void_p, C.POINTER(Outputs), C.c_void_p]
+                                              C.c_void_p, C.c_void_p, C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_get_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.mpcb_last_handover_count.argtypes = [C.c_void_p]
         lib.mpcb_solve_unconstrained_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
@@ -207,20 +207,22 @@ class BatchedPlanner:
 
     # -- solves ----------------------------------------------------------------
     def prepare_coupled(self, x0, y0, speed, feet_x=None, feet_y=None, swing0=None, com0=None,
-                        rows_pqr=None, zref_phase=None):
+                        rows_pqr=None, zref_phase=None, height=None):
         """Uploads one batch of coupled inputs; returns an opaque (B, struct, keepalive).
         rows_pqr [B, m, 3] replaces the footstep inputs by caller-built polygon rows;
-        zref_phase [B, 2*steps+1, 2] overrides the centroid ZMP reference (COUPLED_REF)."""
+        zref_phase [B, 2*steps+1, 2] overrides the centroid ZMP reference (COUPLED_REF);
+        height [B] gives every instance its own CoM height (COUPLED_JERK / COUPLED_VEL)."""
         f64, i32 = self._torch.float64, self._torch.int32
         ts = dict(x0=self._dev(x0, f64), y0=self._dev(y0, f64), speed=self._dev(speed, f64),
                   feet_x=self._dev(feet_x, f64), feet_y=self._dev(feet_y, f64),
                   swing0=self._dev(swing0, i32), com0=self._dev(com0, f64),
-                  rows_pqr=self._dev(rows_pqr, f64), zref_phase=self._dev(zref_phase, f64))
+                  rows_pqr=self._dev(rows_pqr, f64), zref_phase=self._dev(zref_phase, f64),
+                  height=self._dev(height, f64))
         B = ts["x0"].shape[0]
         nph = 2 * self.params.number_of_steps + 1
         shapes = dict(x0=(B, 3), y0=(B, 3), speed=(B, 2), feet_x=(B, 4), feet_y=(B, 4),
                       swing0=(B,), com0=(B, 2), rows_pqr=(B, self.num_constraints, 3),
-                      zref_phase=(B, nph, 2))
+                      zref_phase=(B, nph, 2), height=(B,))
         ci = CoupledInputs()
         for k, t in ts.items():
             if t is None:
@@ -244,11 +246,11 @@ class BatchedPlanner:
         return res
 
     def solve_coupled(self, x0, y0, speed, feet_x=None, feet_y=None, swing0=None, com0=None,
-                      rows_pqr=None, zref_phase=None, outputs=DEFAULT_OUTPUTS, stream=None):
+                      rows_pqr=None, zref_phase=None, height=None, outputs=DEFAULT_OUTPUTS, stream=None):
         """computeSteps + solveQPConstraintCoupled + trajectory read-out for B instances.
         Returns a dict of device tensors (asynchronous on `stream`)."""
         prepared = self.prepare_coupled(x0, y0, speed, feet_x, feet_y, swing0, com0, rows_pqr,
-                                        zref_phase)
+                                        zref_phase, height)
         return self.solve_coupled_prepared(prepared, outputs=outputs, stream=stream)
 
     def host_output_arrays(self, B, outputs=DEFAULT_OUTPUTS, pinned=False):
@@ -328,10 +330,12 @@ class BatchedPlanner:
         _check(load_library().mpcb_solve_coupled_multi(hs, len(planners), B, C.byref(ci), C.byref(o)))
         return res
 
-    def prepare_box(self, x0, zmin, zmax):
+    def prepare_box(self, x0, zmin, zmax, height=None):
         f64 = self._torch.float64
-        ts = (self._dev(x0, f64), self._dev(zmin, f64), self._dev(zmax, f64))
+        ts = (self._dev(x0, f64), self._dev(zmin, f64), self._dev(zmax, f64), self._dev(height, f64))
         B = ts[0].shape[0]
+        if ts[3] is not None and tuple(ts[3].shape) != (B,):
+            raise ValueError("height must be [B]")
         if tuple(ts[0].shape) != (B, 3) or tuple(ts[1].shape) != (B, self.horizon) or \
                 tuple(ts[2].shape) != (B, self.horizon):
             raise ValueError("x0 must be [B,3]; zmin, zmax must be [B,horizon]")
@@ -343,13 +347,14 @@ class BatchedPlanner:
             out = self._alloc_outputs(B, outputs)
         res, o = out
         _check(load_library().mpcb_solve_box_device(self._h, B, ts[0].data_ptr(), ts[1].data_ptr(),
-                                                    ts[2].data_ptr(), C.byref(o),
+                                                    ts[2].data_ptr(),
+                                                    None if ts[3] is None else ts[3].data_ptr(), C.byref(o),
                                                     self._stream(stream)))
         return res
 
-    def solve_box(self, x0, zmin, zmax, outputs=DEFAULT_OUTPUTS, stream=None):
+    def solve_box(self, x0, zmin, zmax, height=None, outputs=DEFAULT_OUTPUTS, stream=None):
         """solveQPconstraint for B one-axis instances; results are in the *_x outputs."""
-        return self.solve_box_prepared(self.prepare_box(x0, zmin, zmax), outputs=outputs,
+        return self.solve_box_prepared(self.prepare_box(x0, zmin, zmax, height), outputs=outputs,
                                        stream=stream)
 
     def solve_unconstrained(self, x0, zmp_ref, outputs=("jerk_x", "zmp_x", "com_x", "com_xd", "status"),

@@ -694,3 +694,48 @@ def test_kkt_conditions_from_an_independent_assembly(P, oracle):
         k = _kkt(Gs, g0s, Cn, ci0, np.concatenate([os_["jerk_x"][i], os_["slacks"][i]]), os_["active_idx"][i, :na],
                  os_["multipliers"][i, :na])
         assert k["stationarity"] < 1e-9 and k["primal"] > -1.0 and k["dual"] > -1e-9 and k["complementarity"] < 1e-6, k
+
+
+def test_height_per_instance_vs_oracle(P, oracle):
+    """`actual_height` is an argument of every solve call in the reference (MPCPlanner.cpp:493-502,
+    516); one handle serves a batch whose instances all have different heights (velocity, jerk-only
+    and box forms, both kernels), each compared with the CPU restatement run at that height."""
+    N, steps = 200, 20
+    for form_name, B, mode in (("COUPLED_VEL", 24, 0), ("COUPLED_JERK", 8, 0), ("COUPLED_VEL", 6, 1)):
+        bt = batches.coupled_batch(B, first=41000)
+        height = 0.4 + 0.2 * batches.SplitMix(np.arange(B), seed=7).uniform()
+        pl = P.BatchedPlanner(N, formulation=getattr(P, form_name), weight_R=0.01, weight_Q=1.0,
+                              number_of_steps=steps, height=0.5, solver_mode=mode)
+        o = _np(pl.solve_coupled(height=height, **bt))
+        refs = [oracle.coupled_batch(oracle.params(N, R=0.01, Q=1.0, height=float(height[i]), iter_cap=4000),
+                                     getattr(oracle, form_name), steps, 1000, bt["x0"][i:i + 1], bt["y0"][i:i + 1],
+                                     bt["speed"][i:i + 1], bt["feet_x"][i:i + 1], bt["feet_y"][i:i + 1],
+                                     bt["swing0"][i:i + 1]) for i in range(B)]
+        ref = {k: np.concatenate([r[k] for r in refs]) for k in refs[0] if refs[0][k] is not None}
+        _check_coupled(o, ref, B)
+        # and the heights matter: the same batch at the handle's height gives another plan
+        o5 = _np(pl.solve_coupled(**bt))
+        assert _rel(o5["jerk_x"], o["jerk_x"]) > 1e-4
+        same = _np(pl.solve_coupled(height=np.full(B, 0.5), **bt))
+        assert _rel(same["jerk_x"], o5["jerk_x"]) < 1e-9 and np.array_equal(same["active_idx"], o5["active_idx"])
+    # box form, through both of its kernels (the infeasible draws go to the dense one)
+    Bb, Nb = 96, 100
+    bb = batches.decoupled_batch(Bb, first=500)
+    hb = 0.4 + 0.2 * batches.SplitMix(np.arange(Bb), seed=9).uniform()
+    pb = P.BatchedPlanner(Nb, formulation=P.BOX_1D, weight_R=1.0)
+    ob = _np(pb.solve_box(bb["y0"], bb["ymin"], bb["ymax"], height=hb))
+    ox = _np(pb.solve_box(bb["x0"], bb["xmin"], bb["xmax"], height=hb))
+    for i in range(Bb):
+        rb = oracle.box_batch(oracle.params(Nb, R=1.0, height=float(hb[i]), iter_cap=3000), bb["x0"][i:i + 1],
+                              bb["y0"][i:i + 1], bb["xmin"][i:i + 1], bb["xmax"][i:i + 1], bb["ymin"][i:i + 1],
+                              bb["ymax"][i:i + 1])
+        for ax, og, key in ((0, ox, "jerk_x"), (1, ob, "jerk_y")):
+            assert og["status"][i] == rb["status"][0, ax]
+            if rb["status"][0, ax] == 0:
+                na = rb["n_active"][0, ax]
+                assert og["iters"][i] == rb["iters"][0, ax]
+                assert list(og["active_idx"][i, :og["n_active"][i]]) == list(rb["active"][0, ax, :na])
+                assert _rel(og["jerk_x"][i], rb[key][0]) < RTOL
+    ref_handle = P.BatchedPlanner(N, formulation=P.COUPLED_REF, weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
+    with pytest.raises(P.MpcError, match="COUPLED_REF"):
+        ref_handle.solve_coupled(height=np.full(4, 0.5), **batches.coupled_batch(4))
