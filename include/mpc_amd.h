@@ -111,7 +111,8 @@ typedef struct {
     const double  *rows_pqr;  /* [B][m][3] or NULL                                       */
     /* Optional ZMP reference for COUPLED_REF, constant over each phase of computeSteps
      * (2*number_of_steps + 1 phases: four-stance, three-stance, ..., trailing knots);
-     * NULL = centroid of the stance feet (computeCentroid).  Required with rows_pqr.       */
+     * NULL = centroid of the stance feet (computeCentroid).  With rows_pqr give this or
+     * zref_knot.                                                                          */
     const double  *zref_phase; /* [B][nphase][2] or NULL                                 */
     /* Optional CoM height per instance: the `actual_height` argument the reference takes on
      * every solve call (MPCPlanner.cpp:493-502,516).  NULL = mpcb_params.height for all.
@@ -119,6 +120,11 @@ typedef struct {
      * height, so one handle serves every height); COUPLED_REF keeps the per-handle height.
      * The first call that passes heights builds a few more tables (one-off, ~0.1 s).      */
     const double  *height;     /* [B] or NULL                                             */
+    /* Optional ZMP reference for COUPLED_REF that changes from knot to knot: the zmp_ref_x,
+     * zmp_ref_y vectors of solveQPConstraintCoupledRef (MPCPlanner.cpp:632-640), any values.
+     * Excludes zref_phase.  Costs one N x N table sweep per instance where the per-phase form
+     * needs nphase rows; the first call that passes it builds its tables (one-off).          */
+    const double  *zref_knot;  /* [B][N][2] or NULL                                       */
 } mpcb_coupled_inputs;
 
 /* Outputs.  Any pointer may be NULL (that output is skipped). */

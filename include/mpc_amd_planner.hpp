@@ -671,7 +671,8 @@ class MPCPlanner {
         need(A.rows() == m, "A does not have the rows computeSteps produces for this horizon/steps");
         // Row r of A is (p at column k, q at column k+N) for the knot k computeSteps gave it
         // (MPCPlanner.cpp:1072-1079); rebuild k from the swing flags of the last computeSteps.
-        std::vector<double> rows((size_t)m * 3), zph((size_t)nph * 2, 0.0);
+        std::vector<double> rows((size_t)m * 3), zph((size_t)nph * 2, 0.0), zkn;
+        bool ref_by_phase = true;
         const int pd = (N / number_of_steps_) / 2;
         int r = 0;
         for (int k = 0; k < N; k++) {
@@ -686,8 +687,9 @@ class MPCPlanner {
             if (zrefx) {
                 const int ph = (pd > 0 && k < 2 * pd * number_of_steps_) ? k / pd : 2 * number_of_steps_;
                 const int first = (ph == 2 * number_of_steps_) ? 2 * pd * number_of_steps_ : ph * pd;
-                need((*zrefx)[k] == (*zrefx)[first] && (*zrefy)[k] == (*zrefy)[first],
-                     "the ZMP reference must be constant over each footstep phase");
+                // constant over every footstep phase (computeCentroid's is): the per-phase form;
+                // anything else goes to the library knot by knot
+                if ((*zrefx)[k] != (*zrefx)[first] || (*zrefy)[k] != (*zrefy)[first]) ref_by_phase = false;
                 zph[2 * ph] = (*zrefx)[k];
                 zph[2 * ph + 1] = (*zrefy)[k];
             }
@@ -700,11 +702,23 @@ class MPCPlanner {
         in.y0 = y0.data();
         in.speed = speed.data();
         in.rows_pqr = rows.data();
-        in.zref_phase = zrefx ? zph.data() : nullptr;
+        if (zrefx && ref_by_phase) in.zref_phase = zph.data();
+        if (zrefx && !ref_by_phase) {
+            zkn = interleave(*zrefx, *zrefy);
+            in.zref_knot = zkn.data();
+        }
         in.height = height_in_tables(formulation) ? nullptr : &height;
         mpcb_outputs o = outputs(jerk_x.data(), jerk_y.data());
         check(mpcb_solve_coupled(h, 1, &in, &o));
         finish(o);
+    }
+    static std::vector<double> interleave(const VectorXd &a, const VectorXd &b) { // [k][x, y]
+        std::vector<double> v(2 * a.size());
+        for (size_t k = 0; k < a.size(); k++) {
+            v[2 * k] = a[k];
+            v[2 * k + 1] = b[k];
+        }
+        return v;
     }
     static int rows_of_schedule(int N, int steps) { // rows computeSteps leaves in A (:1324-1326)
         const int pd = (N / steps) / 2;
@@ -742,14 +756,8 @@ class MPCPlanner {
             rows[3 * s + 2] = b[r];
             slot_row[s] = r;
         }
-        std::vector<double> zph(2, 0.0);
-        if (zrefx) {
-            for (int k = 0; k < N; k++)
-                need((*zrefx)[k] == (*zrefx)[0] && (*zrefy)[k] == (*zrefy)[0],
-                     "without a footstep schedule the ZMP reference must be constant over the horizon");
-            zph[0] = (*zrefx)[0];
-            zph[1] = (*zrefy)[0];
-        }
+        std::vector<double> zkn;
+        if (zrefx) zkn = interleave(*zrefx, *zrefy); // no footstep phases here: the reference goes knot by knot
         jerk_x.assign(N, 0.0);
         jerk_y.assign(N, 0.0);
         mpcb_coupled_inputs in = {};
@@ -757,7 +765,7 @@ class MPCPlanner {
         in.y0 = y0.data();
         in.speed = speed.data();
         in.rows_pqr = rows.data();
-        in.zref_phase = zrefx ? zph.data() : nullptr;
+        in.zref_knot = zrefx ? zkn.data() : nullptr;
         in.height = height_in_tables(formulation) ? nullptr : &height;
         mpcb_outputs o = outputs(jerk_x.data(), jerk_y.data());
         last_active_.assign(4 * N, -1);

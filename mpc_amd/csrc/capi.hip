@@ -72,6 +72,8 @@ struct mpcb_handle_s {
     hipEvent_t count_event = nullptr;
     bool count_pending = false;
     hipStream_t own_stream = nullptr; // stream of the host-pointer entry points
+    // COUPLED_REF with a free (per-knot) ZMP reference: Sp, Wp, F2, F3 with one segment per knot
+    const double *knot_Sp = nullptr, *knot_Wp = nullptr, *knot_F2 = nullptr, *knot_F3 = nullptr;
     // device arena of the host-pointer entry points: grown when a batch needs more, kept
     // between calls (so they neither allocate nor free in steady state)
     void *stage_dev = nullptr;
@@ -241,6 +243,7 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
     ds.steps = hs.steps;
     ds.phase_knots = hs.phase_knots;
     ds.nphase = hs.nphase;
+    ds.nref = hs.nphase;
     const int n = hs.nvar;
     ds.iter_cap = params->iter_cap > 0 ? params->iter_cap : 50 * (n + hs.m);
     std::memcpy(ds.F, hs.F, sizeof(ds.F));
@@ -358,9 +361,48 @@ int ensure_height_tables(mpcb_handle h) {
     return 0;
 }
 
+// COUPLED_REF tables for a reference that changes from knot to knot: the per-phase tables
+// (setup.cpp) with every knot a phase of its own -- Sp = Qs S, Wp = Qs W^T,
+// F2[a][k] = -Qs (Zu Kx)[k][a], F3 = -Qs^2 S / 2 (g0 gains -Qs Zu' zref, MPCPlanner.cpp:731-735).
+// Built and uploaded the first time such a reference is passed.
+int ensure_knot_reference_tables(mpcb_handle h) {
+    if (h->knot_Sp) return 0;
+    const mpcb::HostSetup &hs = h->hs;
+    const size_t N = (size_t)hs.N;
+    const double Qs = h->params.weight_Qs;
+    std::vector<double> Sp(N * N), Wp(N * N), F2(4 * N), F3(N * N);
+    for (size_t i = 0; i < N * N; i++) {
+        Sp[i] = Qs * hs.S[i];
+        Wp[i] = Qs * hs.Wt[i];
+        F3[i] = -Qs * Qs * hs.S[i] / 2;
+    }
+    for (size_t k = 0; k < N; k++)
+        for (size_t a = 0; a < 4; a++)
+            F2[a * N + k] = -Qs * (hs.Kz[k * 4 + a] - (a < 3 ? hs.zx[k * 3 + a] : 0.0));
+    int rc;
+    if ((rc = upload_to(h, Wp, &h->knot_Wp)) || (rc = upload_to(h, F2, &h->knot_F2)) ||
+        (rc = upload_to(h, F3, &h->knot_F3)) || (rc = upload_to(h, Sp, &h->knot_Sp)))
+        return rc;
+    return 0;
+}
+
 // first stage (wave per QP), then the dense kernel over whatever it handed over
 int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &out, int B,
                      const mpcb::DenseWs &ws, int dense_grid, hipStream_t stream) {
+    if (di.zref_knot_mode) {
+        // same kernels, the reference's segments are the knots
+        mpcb::DevSetup ds = h->ds;
+        ds.Sp = h->knot_Sp;
+        ds.Wp = h->knot_Wp;
+        ds.F2 = h->knot_F2;
+        ds.F3 = h->knot_F3;
+        ds.nref = ds.N;
+        HIP_TRY(hipMemsetAsync(ws.count, 0, sizeof(int), stream));
+        if (h->params.solver_mode == MPCB_MODE_DENSE) HIP_TRY(mpcb::launch_list_all(ws, B, stream));
+        else HIP_TRY(mpcb::launch_zspace(ds, di, out, B, ws, stream));
+        HIP_TRY(mpcb::launch_dense(ds, di, out, ws, dense_grid, stream));
+        return 0;
+    }
     // the slack formulation keeps about 2N rows active: beyond the first stage's capacity
     if (h->params.solver_mode == MPCB_MODE_DENSE || h->params.formulation == MPCB_BOX_SLACK) {
         HIP_TRY(mpcb::launch_list_all(ws, B, stream));
@@ -453,8 +495,6 @@ static int coupled_arguments(mpcb_handle h, int32_t B, const mpcb_coupled_inputs
     if (!in->x0 || !in->y0 || !in->speed) return fail(MPCB_E_ARG, "missing coupled input array");
     if (!in->rows_pqr && (!in->feet_x || !in->feet_y || !in->swing0))
         return fail(MPCB_E_ARG, "feet_x, feet_y and swing0 are required unless rows_pqr is given");
-    if (in->rows_pqr && form == MPCB_COUPLED_REF && !in->zref_phase)
-        return fail(MPCB_E_ARG, "COUPLED_REF with rows_pqr needs zref_phase");
     if ((out->active_idx || out->multipliers) && out->active_stride <= 0)
         return fail(MPCB_E_ARG, "active_stride must be positive");
     std::memset(&di, 0, sizeof(di));
@@ -468,6 +508,14 @@ static int coupled_arguments(mpcb_handle h, int32_t B, const mpcb_coupled_inputs
     di.rows_pqr = in->rows_pqr;
     di.zref_phase = in->zref_phase;
     di.height = in->height;
+    if (in->zref_knot) {
+        if (form != MPCB_COUPLED_REF) return fail(MPCB_E_ARG, "zref_knot is an input of COUPLED_REF only");
+        if (in->zref_phase) return fail(MPCB_E_ARG, "give zref_phase or zref_knot, not both");
+        di.zref_phase = in->zref_knot; // the kernels index it by segment; here the segments are the knots
+        di.zref_knot_mode = 1;
+    }
+    if (in->rows_pqr && form == MPCB_COUPLED_REF && !in->zref_phase && !in->zref_knot)
+        return fail(MPCB_E_ARG, "COUPLED_REF with rows_pqr needs zref_phase or zref_knot");
     if (in->height && form == MPCB_COUPLED_REF)
         return fail(MPCB_E_ARG, "COUPLED_REF takes its height from mpcb_params: its Hessian depends on it");
     return 0;
@@ -480,6 +528,7 @@ int mpcb_solve_coupled_device(mpcb_handle h, int32_t B, const mpcb_coupled_input
     if (rc || B == 0) return rc;
     DeviceGuard guard(h->params.device);
     if (di.height && (rc = ensure_height_tables(h))) return rc;
+    if (di.zref_knot_mode && (rc = ensure_knot_reference_tables(h))) return rc;
     return solve_two_stage(h, di, *out, B, (hipStream_t)stream);
 }
 
@@ -496,6 +545,9 @@ int mpcb_solve_coupled_device_noalloc(mpcb_handle h, int32_t B, const mpcb_coupl
                                     " variables per QP (horizon 200)");
     if (h->params.device >= MAX_DEVICES || !g_scratch[h->params.device])
         return fail(MPCB_E_ARG, "mpcb_solve_coupled_device_noalloc: no scratch on this device");
+    if (di.zref_knot_mode && !h->knot_Sp)
+        return fail(MPCB_E_ARG, "mpcb_solve_coupled_device_noalloc: the tables for a per-knot ZMP reference are built "
+                                "(and allocated) by the first mpcb_solve_coupled[_device] call that passes one");
     if (di.height && !h->ds.Spp)
         return fail(MPCB_E_ARG, "mpcb_solve_coupled_device_noalloc: the tables for per-instance heights are built (and "
                                 "allocated) by the first mpcb_solve_coupled[_device] call that passes heights");
@@ -536,7 +588,7 @@ int mpcb_solve_coupled_multi(const mpcb_handle *handles, int32_t n_handles, int3
         mpcb_outputs so = *out;
 #define IN_(field, w) if (si.field) si.field += first * (w);
         IN_(x0, 3) IN_(y0, 3) IN_(speed, 2) IN_(feet_x, 4) IN_(feet_y, 4) IN_(swing0, 1) IN_(com0, 2)
-        IN_(rows_pqr, m * 3) IN_(zref_phase, P * 2) IN_(height, 1)
+        IN_(rows_pqr, m * 3) IN_(zref_phase, P * 2) IN_(height, 1) IN_(zref_knot, N * 2)
 #undef IN_
 #define OUT_(field, w) if (so.field) so.field += first * (w);
         OUT_(jerk_x, N) OUT_(jerk_y, N) OUT_(com_x, N) OUT_(com_y, N) OUT_(com_xd, N) OUT_(com_yd, N)
@@ -691,7 +743,7 @@ int mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, 
             (rc = st.in(in->com0, b * 2, &di.com0)) ||
             (rc = st.in(in->rows_pqr, b * (size_t)h->hs.m * 3, &di.rows_pqr)) ||
             (rc = st.in(in->zref_phase, b * (size_t)h->hs.nphase * 2, &di.zref_phase)) ||
-            (rc = st.in(in->height, b, &di.height)))
+            (rc = st.in(in->height, b, &di.height)) || (rc = st.in(in->zref_knot, b * N * 2, &di.zref_knot)))
             return rc;
         return stage_outputs(st, *out, dout, b, N);
     };

@@ -18,6 +18,7 @@
 // The rotation angles of add_constraint (a sequential hypot chain in the reference)
 // are computed in parallel from suffix norms of d.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 
 #include "device_common.h"
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
     double *zc = hi + N;                                                 // Toeplitz column of Zu
     double *tab = zc + N;                                                // POLY: [phase][edge][p,q,r]
     double *cref = tab + (POLY ? sd.nphase * 12 : 0);                    // POLY: [phase][x,y]
-    double *red = cref + (POLY ? sd.nphase * 2 : 0);
+    double *red = cref + (POLY ? 2 * max(sd.nphase, sd.nref) : 0);
     int *redk = reinterpret_cast<int *>(red + 2 * RED_D);
     int *A = redk + 2 * RED_I, *A_old = A + (n + 1), *iai = A_old + (n + 1);
     int flip = 0;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
                 for (int phb = 0; phb < sd.nphase; phb += T)
                     polygon_phase(sd, in, inst, wx[3], wy[3], phb + tid, tab, cref);
             if (in.zref_phase)
-                for (int i = tid; i < 2 * sd.nphase; i += T) cref[i] = in.zref_phase[(size_t)inst * 2 * sd.nphase + i];
+                for (int i = tid; i < 2 * sd.nref; i += T) cref[i] = in.zref_phase[(size_t)inst * 2 * sd.nref + i];
         } else {
             for (int k = tid; k < N; k += T) {
                 lo[k] = in.zmin[(size_t)inst * N + k];
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
             double v = kx[0] * w[0] + kx[1] * w[1] + kx[2] * w[2] + kx[3] * w[3];
             if constexpr (POLY) {
                 if (sd.Wp)
-                    for (int p2 = 0; p2 < sd.nphase; p2++)
+                    for (int p2 = 0; p2 < sd.nref; p2++)
                         v += cref[2 * p2 + (i < N ? 0 : 1)] * sd.Wp[(size_t)p2 * N + k];
             }
             x[i] = v;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
         double f;
         {
             double fp = 0.0;
-            for (int pb = 0; pb < (sd.F2 ? sd.nphase : 1); pb += T)
+            for (int pb = 0; pb < (sd.F2 ? sd.nref : 1); pb += T)
                 fp += unconstrained_cost_part(sd, wx, cref, 0, pb + tid, pb + tid == 0) +
                       unconstrained_cost_part(sd, wy, cref, 1, pb + tid, pb + tid == 0);
             f = block_sum(fp, red, tid, flip);
@@ -1048,7 +1049,8 @@ __global__ void list_all_kernel(int *list, int *count, int B) {
 
 size_t dense_lds_bytes(const DevSetup &sd, bool ldsj) {
     const size_t N = sd.N, n = sd.nvar, m = sd.m;
-    size_t doubles = 5 * n + 3 * (n + 1) + 3 * n + (n + 1) + m + 5 * N + (size_t)sd.nphase * 14 + 2 * RED_D;
+    size_t doubles = 5 * n + 3 * (n + 1) + 3 * n + (n + 1) + m + 5 * N + (size_t)sd.nphase * 12 +
+                     2 * (size_t)(sd.form == MPCB_COUPLED_REF ? std::max(sd.nphase, sd.N) : sd.nphase) + 2 * RED_D;
     size_t ints = 2 * RED_I + 2 * (n + 1) + 2 * m;
     size_t bytes = doubles * 8 + ints * 4 + 64;
     if (ldsj) bytes += (n * (n | 1) + n * (n + 3) / 2 + 2 + n) * 8;

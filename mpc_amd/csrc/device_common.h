@@ -290,7 +290,7 @@ __device__ inline void polygon_phase(const DevSetup &sd, const DevIn &in, int in
 
 // Cost of the unconstrained minimiser, f = 1/2 g0'x (eiquadprog.hpp:191), for one axis:
 // w'Fw, plus for the ZMP-reference formulation the terms in the per-phase reference c.
-// Call with every index ph in [0, nphase) covered once over the calling threads and
+// Call with every index ph in [0, nref) covered once over the calling threads and
 // sum the results; `base` adds w'Fw (pass true from exactly one thread).
 __device__ __forceinline__ double unconstrained_cost_part(const DevSetup &sd, const double w[4],
                                                           const double *cref, int axis, int ph,
@@ -302,11 +302,11 @@ __device__ __forceinline__ double unconstrained_cost_part(const DevSetup &sd, co
 #pragma unroll
             for (int b = 0; b < 4; b++) f += sd.F[a * 4 + b] * w[a] * w[b];
     }
-    if (sd.F2 && ph < sd.nphase) {
+    if (sd.F2 && ph < sd.nref) {
         double t = 0.0;
 #pragma unroll
-        for (int a = 0; a < 4; a++) t += w[a] * sd.F2[a * sd.nphase + ph];
-        for (int p2 = 0; p2 < sd.nphase; p2++) t += sd.F3[ph * sd.nphase + p2] * cref[2 * p2 + axis];
+        for (int a = 0; a < 4; a++) t += w[a] * sd.F2[a * sd.nref + ph];
+        for (int p2 = 0; p2 < sd.nref; p2++) t += sd.F3[ph * sd.nref + p2] * cref[2 * p2 + axis];
         f += t * cref[2 * ph + axis];
     }
     return f;

@@ -24,6 +24,8 @@ struct DevSetup {
     // knots of one phase, [nphase][N], weight Qs folded in; cost terms F2 [4][nphase],
     // F3 [nphase][nphase]
     const double *Sp, *Wp, *F2, *F3;
+    int nref;                         // segments of the ZMP reference: rows of Sp / Wp, columns of F2, order of
+                                      // F3 -- the footstep phases (nphase) or, for a free reference, the knots (N)
     // per-instance heights (else NULL): S = Spp - c Sps + c^2 Saa, W^T = Wtp - c Wta,
     // Kz = Kzp - c Kza with c = height / gravity
     const double *Spp, *Sps, *Saa, *Wtp, *Wta, *Kzp, *Kza;
@@ -42,8 +44,9 @@ struct DevIn {
     const int *swing0;
     const double *zmin, *zmax;        // BOX_1D
     const double *rows_pqr;           // optional [B][m][3]: caller-built polygon rows
-    const double *zref_phase;         // optional [B][nphase][2]: ZMP reference per phase
+    const double *zref_phase;         // optional [B][nref][2]: ZMP reference per segment
     const double *height;             // optional [B]: CoM height per instance (needs the height tables)
+    int zref_knot_mode;               // zref_phase holds [B][N][2], one reference per knot
 };
 
 // Hand-over from the wave-per-QP kernel to the dense kernel, and the dense kernel's

@@ -20,6 +20,7 @@
 // them, in registers.  Cross-lane data goes through the wave's private LDS slice
 // or through wave shuffles.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -183,7 +184,8 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     long long stamp_acc[16] = {0};
     long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
-    const int tab_doubles = POLY ? sd.nphase * 14 + 12 : 0; // one padding phase after the last
+    // polygon table (one padding phase after the last) + the ZMP reference per segment
+    const int tab_doubles = POLY ? (sd.nphase + 1) * 12 + 2 * max(sd.nphase, sd.nref) : 0;
     const int per_wave = (int)(sizeof(WaveState) / 8) + tab_doubles;
     WaveState &W = *reinterpret_cast<WaveState *>(smem + (size_t)wv * per_wave);
     double *tab = smem + (size_t)wv * per_wave + sizeof(WaveState) / 8; // [phase][edge][p,q,r]
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
             for (int pbase = 0; pbase < sd.nphase; pbase += 64)
                 polygon_phase(sd, feetx, feety, com0x, com0y, swing_first, wx[3], wy[3], pbase + lane, tab, cref);
         if (in.zref_phase)
-            for (int i = lane; i < 2 * sd.nphase; i += 64) cref[i] = in.zref_phase[(size_t)inst * 2 * sd.nphase + i];
+            for (int i = lane; i < 2 * sd.nref; i += 64) cref[i] = in.zref_phase[(size_t)inst * 2 * sd.nref + i];
         if constexpr (!ROWS) {
             // Rows that do not exist evaluate to +inf without a test: the fourth edge of a
             // three-foot phase, and every edge of the padding phase that the lanes past
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     // v += sum over phases of (reference of the phase) * Mp[phase, :], eight phases' loads in
     // flight at a time (ZMP-reference formulation)
     auto accum_phases = [&](const double *Mp, double *vx, double *vy) {
-        const int P = sd.nphase;
+        const int P = sd.nref;
         for (int p0 = 0; p0 < P; p0 += 8) {
             double cxr[8], cyr[8], mv[8][NPL];
 #pragma unroll
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     double f;
     {
         double fp = 0.0;
-        for (int pb = 0; pb < (sd.F2 ? sd.nphase : 1); pb += 64)
+        for (int pb = 0; pb < (sd.F2 ? sd.nref : 1); pb += 64)
             fp += unconstrained_cost_part(sd, wx, cref, 0, pb + lane, pb + lane == 0) +
                   unconstrained_cost_part(sd, wy, cref, 1, pb + lane, pb + lane == 0);
         f = wave_sum(fp);
@@ -1030,7 +1032,8 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
 template <int NPL, bool POLY, bool ROWS, bool HV>
 hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
                       const DenseWs &ws, hipStream_t stream) {
-    const size_t per_wave = sizeof(WaveState) + (POLY ? ((size_t)sd.nphase * 14 + 12) * 8 : 0);
+    const size_t per_wave = sizeof(WaveState) +
+                            (POLY ? ((size_t)(sd.nphase + 1) * 12 + 2 * (size_t)std::max(sd.nphase, sd.nref)) * 8 : 0);
     // One wave (= one QP) per workgroup: waves never wait for each other, so a workgroup's LDS
     // and wave slot are released the moment its QP is done instead of when the slowest of
     // several is (iteration counts differ by 2-3x between instances).

@@ -5,6 +5,7 @@
 //   qp        tests/unconstrainedQP/testPlanner.cpp                              (defaults)
 // Each writes the same "time value" text files into $HOME through saveTraj and prints a
 // few values as key=value lines for the test that runs it.
+#include <cmath>
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
@@ -58,13 +59,34 @@ static int coupled() {
     myPlanner.saveTraj("centroidX.txt", centroidX);
     myPlanner.saveTraj("centroidY.txt", centroidY);
     myPlanner.saveTraj("footPosLF.txt", feetStates[LF].x, feetStates[LF].y);
-    myPlanner.saveTraj("footHoldsLF.txt", footHolds[LF].x, footHolds[LF].y);
+    myPlanner.saveTraj("footPosRF.txt", feetStates[RF].x, feetStates[RF].y);
+    myPlanner.saveTraj("footPosLH.txt", feetStates[LH].x, feetStates[LH].y);
+    myPlanner.saveTraj("footPosRH.txt", feetStates[RH].x, feetStates[RH].y);
+    myPlanner.saveTraj("footHoldsLF.txt", footHolds[LF].x, footHolds[LF].y, 2 * number_of_steps);
+    myPlanner.saveTraj("footHoldsRF.txt", footHolds[RF].x, footHolds[RF].y, 2 * number_of_steps);
+    myPlanner.saveTraj("footHoldsLH.txt", footHolds[LH].x, footHolds[LH].y, 2 * number_of_steps);
+    myPlanner.saveTraj("footHoldsRH.txt", footHolds[RH].x, footHolds[RH].y, 2 * number_of_steps);
     myPlanner.saveTraj("swingLF.txt", feetStates[LF].swing);
+    myPlanner.saveTraj("swingRF.txt", feetStates[RF].swing);
+    myPlanner.saveTraj("swingLH.txt", feetStates[LH].swing);
+    myPlanner.saveTraj("swingRH.txt", feetStates[RH].swing);
     double mn = viol[0];
     for (double v : viol) mn = v < mn ? v : mn;
     std::printf("jerk_x0=%.9g\njerk_x1=%.9g\njerk_x2=%.9g\ncom_x199=%.9g\nmin_margin=%.9g\nn_active=%d\ncost=%.12g\n",
                 jerk_x[0], jerk_x[1], jerk_x[2], com_x[199], mn, (int)myPlanner.lastActiveSet().size(),
                 myPlanner.lastCost());
+    // a ZMP reference that is not constant over the footstep phases (the reference accepts any
+    // vector, MPCPlanner.cpp:632-640): the centroid plus a slow lateral sway
+    {
+        VectorXd swayX = centroidX, swayY = centroidY, jx, jy;
+        for (int k = 0; k < horizon_size; k++) swayY[k] += 0.05 * std::sin(0.07 * k);
+        myPlanner.solveQPConstraintCoupledRef(height, initial_state_x, initial_state_y, swayX, swayY, A, b, userSpeed,
+                                              jx, jy);
+        myPlanner.saveTraj("sway_ref_y.txt", swayY, false);
+        myPlanner.saveTraj("sway_jerk_x.txt", jx, false);
+        myPlanner.saveTraj("sway_jerk_y.txt", jy, false);
+        std::printf("sway_cost=%.12g\nsway_n_active=%d\n", myPlanner.lastCost(), (int)myPlanner.lastActiveSet().size());
+    }
     // the velocity formulation on the same polygons (constraints bind)
     myPlanner.solveQPConstraintCoupled(height, initial_state_x, initial_state_y, A, b, userSpeed, jerk_x, jerk_y);
     std::printf("vel_n_active=%d\nvel_cost=%.12g\nvel_jerk_x0=%.12g\n", (int)myPlanner.lastActiveSet().size(),

@@ -475,6 +475,26 @@ def test_cpp_dropin_drivers(P, tmp_path):
     t, v = lines[199].split()
     assert float(t) == pytest.approx(19.9) and float(v) == pytest.approx(g["com_x_199"], rel=2e-6)
     assert len(open(tmp_path / "footPosLF.txt").read().splitlines()[0].split()) == 3
+    # every file the reference's driver writes (testPlannerXYconstraintCoupled.cpp:135-165), so that
+    # plotTrajXYconstraintCoupled.m finds what it loads
+    expected = ["jerk_x", "jerk_y", "zmp_x", "zmp_y", "com_x", "com_y", "com_xd", "com_yd", "viol", "centroidX",
+                "centroidY"] + [p + leg for p in ("footPos", "footHolds", "swing") for leg in ("LF", "RF", "LH", "RH")]
+    assert len(expected) == 23
+    for name in expected:
+        rows_ = open(tmp_path / (name + ".txt")).read().splitlines()
+        assert len(rows_) == (20 if name.startswith("footHolds") else 200), name
+    # the second Ref solve of the driver: a reference that sways inside the phases, against the
+    # CPU restatement given the same vectors
+    from oracle import oracle as O
+    st = O.compute_steps(200, 20, np.array([0.15, 0.0]), np.array([0.1, 0.2, -0.4, -0.3]),
+                         np.array([1.0, -1.0, 1.0, -1.0]), 0)
+    cx = np.loadtxt(tmp_path / "centroidX.txt")[:, 1]
+    sway = np.loadtxt(tmp_path / "sway_ref_y.txt")[:, 1]
+    ref = O.solve_coupled(O.params(200, R=0.01, Q=1.0, Qs=100.0, height=0.5, iter_cap=4000), O.COUPLED_REF,
+                          np.zeros(3), np.zeros(3), st["A"], st["b"], np.array([0.15, 0.0]), 1000, cx, sway)
+    assert c["sway_n_active"] == ref["info"].n_active
+    assert c["sway_cost"] == pytest.approx(ref["info"].f, rel=1e-6)
+    assert _rel(np.loadtxt(tmp_path / "sway_jerk_y.txt")[:, 1], ref["jerk_y"]) < 2e-5  # 6 printed digits
     d = run("decoupled")
     g = gold["decoupled_default"]
     assert np.allclose([d["jerk_y0"], d["jerk_y1"], d["jerk_y2"]], g["jerk_y_0_2"], rtol=2e-6)
@@ -739,3 +759,46 @@ def test_height_per_instance_vs_oracle(P, oracle):
     ref_handle = P.BatchedPlanner(N, formulation=P.COUPLED_REF, weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
     with pytest.raises(P.MpcError, match="COUPLED_REF"):
         ref_handle.solve_coupled(height=np.full(4, 0.5), **batches.coupled_batch(4))
+
+
+def test_zmp_reference_per_knot_vs_oracle(P, oracle):
+    """solveQPConstraintCoupledRef takes any zmp_ref vectors (MPCPlanner.cpp:632-640, 728-735); the
+    per-knot reference input against the CPU restatement, with weights that make constraints bind,
+    and against the per-phase input where the reference happens to be constant over the phases."""
+    B, N, steps, Qs = 10, 200, 20, 1.0
+    bt = batches.coupled_batch(B, first=51000)
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_REF, weight_R=0.01, weight_Q=1.0, weight_Qs=Qs,
+                          number_of_steps=steps)
+    k = np.arange(N)
+    zk = np.zeros((B, N, 2))
+    p = oracle.params(N, R=0.01, Q=1.0, Qs=Qs, height=0.5, iter_cap=4000)
+    refs = []
+    for i in range(B):
+        st = oracle.compute_steps(N, steps, bt["speed"][i], bt["feet_x"][i], bt["feet_y"][i], bt["swing0"][i])
+        cx, cy = oracle.centroid(st["fx"], st["fy"], st["swing"])
+        zk[i, :, 0] = cx + 0.03 * np.sin(0.05 * k + i)
+        zk[i, :, 1] = cy + 0.2 * np.cos(0.11 * k) * (1 + 0.1 * i)
+        refs.append(oracle.solve_coupled(p, oracle.COUPLED_REF, bt["x0"][i], bt["y0"][i], st["A"], st["b"],
+                                         bt["speed"][i], 1000, zk[i, :, 0], zk[i, :, 1]))
+    for mode in (0, 1):
+        plm = pl if mode == 0 else P.BatchedPlanner(N, formulation=P.COUPLED_REF, weight_R=0.01, weight_Q=1.0,
+                                                    weight_Qs=Qs, number_of_steps=steps, solver_mode=1)
+        o = _np(plm.solve_coupled(zref_knot=zk, **bt))
+        assert max(r["info"].n_active for r in refs) > 0
+        for i, r in enumerate(refs):
+            assert o["status"][i] == r["info"].status and o["iters"][i] == r["info"].iters
+            assert list(o["active_idx"][i, :o["n_active"][i]]) == list(r["active"])
+            assert _rel(o["jerk_x"][i], r["jerk_x"]) < RTOL and _rel(o["jerk_y"][i], r["jerk_y"]) < RTOL
+            assert abs(o["cost"][i] - r["info"].f) <= RTOL * abs(r["info"].f)
+    # a per-knot reference that is constant over each phase = the per-phase input
+    plain = _np(pl.solve_coupled(**bt))  # centroid reference, built in the kernel
+    cz = np.zeros((B, N, 2))
+    for i in range(B):
+        st = oracle.compute_steps(N, steps, bt["speed"][i], bt["feet_x"][i], bt["feet_y"][i], bt["swing0"][i])
+        cz[i, :, 0], cz[i, :, 1] = oracle.centroid(st["fx"], st["fy"], st["swing"])
+    byknot = _np(pl.solve_coupled(zref_knot=cz, **bt))
+    assert np.array_equal(byknot["active_idx"], plain["active_idx"])
+    assert _rel(byknot["jerk_x"], plain["jerk_x"]) < 1e-8 and _rel(byknot["cost"], plain["cost"]) < 1e-8
+    with pytest.raises(P.MpcError, match="COUPLED_REF"):
+        P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, number_of_steps=steps).solve_coupled(
+            zref_knot=zk, **bt)
