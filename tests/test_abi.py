@@ -114,3 +114,15 @@ def test_weak_scaling_shards_two_ranks_gloo(tmp_path):
            "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_eigen_overload_set_compiles():
+    """include/mpc_amd_eigen.hpp (the reference's signatures with Eigen argument types) compiles
+    against <Eigen/Dense> -- the real one where installed, else the stand-in declarations under
+    tests/cpp/mock_eigen -- with the reference's coupled driver calls."""
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    obj = os.path.join(cpp, "eigen_adapter_check.o")
+    if os.path.exists(obj):
+        os.remove(obj)
+    r = subprocess.run(["make", "-C", cpp, "eigen_adapter_check.o"], capture_output=True, text=True)
+    assert r.returncode == 0 and os.path.exists(obj), r.stdout + r.stderr
