@@ -62,11 +62,17 @@ __device__ __forceinline__ double bcast(double v, int src) {
                             __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 
-// value of lane 63 - l (lane reversal through the LDS crossbar)
-__device__ __forceinline__ double lane_reverse(double v, int lane) {
-    const int src = (63 - lane) << 2;
-    return __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(v)),
-                            __builtin_amdgcn_ds_bpermute(src, __double2loint(v)));
+// Inclusive suffix sum over the lanes (lane i receives v_i + ... + v_63), accumulated from the
+// far end: shifts towards lower lanes inside each row of 16, then the totals of the rows above.
+__device__ __forceinline__ double wave_suffix_scan(double v, int lane) {
+    v += dpp_f64<0x101, 0xF>(0.0, v); // row_shl:1
+    v += dpp_f64<0x102, 0xF>(0.0, v); // row_shl:2
+    v += dpp_f64<0x104, 0xF>(0.0, v); // row_shl:4
+    v += dpp_f64<0x108, 0xF>(0.0, v); // row_shl:8
+    const double t1 = bcast(v, 16), t2 = bcast(v, 32), t3 = bcast(v, 48);
+    const int row = lane >> 4;
+    const double above = row == 0 ? (t3 + t2) + t1 : row == 1 ? t3 + t2 : row == 2 ? t3 : 0.0;
+    return v + above;
 }
 
 __device__ __forceinline__ double shift_down(double a0, int lane) { // value of lane + 1
@@ -166,6 +172,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
         int iq = 0, iters = 0, passes = 0, status = MPCB_OK;
         double R_norm = 1.0;
         const double nn = (double)n, mm = (double)m;
+        const double inv_weight_R = nn / sd.traceG1; // the Hessian is weight_R I (MPCPlanner.cpp:262)
         double falg = 2.0 * nn * nn;
         double zm0 = 0.0, zm1 = 0.0; // ZMP at the lane's knots
         bool zmp_current = false;
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
             s11 = hi1 - zm1;
         };
         // Drop working-set position qq (delete_constraint, eiquadprog.hpp:516-592).
-        auto drop_constraint = [&](int qq) {
+        auto drop_constraint = [&](int qq, double &d0, double &d1) {
             const int last = iq - 1; // columns qq .. last take part
             {
                 const double c = (double)(iq - 1 - qq);
@@ -249,6 +256,14 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     cb[i0] = b0c;
                     ca[i1] = a1c;
                     cb[i1] = b1c;
+                    // d = J' n+ follows the columns of J: the same combination, applied to the
+                    // entries the lanes hold (the next pass then needs no product with J)
+                    const double q0 = wave_scan(g0 * d0);
+                    const double q1 = wave_scan(g1 * d1) + lane63(q0);
+                    const double dn0 = lane == 63 ? bcast(d1, 0) : shift_down(d0, lane);
+                    const double dn1 = shift_down(d1, lane);
+                    if (i0 >= qq && i0 <= last) d0 = fma(a0c, q0, b0c * dn0);
+                    if (i1 >= qq && i1 <= last) d1 = fma(a1c, q1, b1c * dn1);
                 }
                 wsync();
                 if (wave < 2) {
@@ -409,6 +424,8 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                 sgn = ip < N ? 1.0 : -1.0;
                 ucand = 0.0;
                 BSTAMP(2);
+                double d0 = 0.0, d1 = 0.0;
+                bool d_valid = false; // d = J' n+ is current (a drop rotates it along with J)
                 for (;;) { // step 2a (l2a)
                     passes++;
                     if (passes > sd.iter_cap) {
@@ -417,32 +434,35 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                         break;
                     }
                     falg += 2.0 * nn * nn + 2.0 * nn * (nn - iq) + (double)iq * iq;
-                    // ---- d = J' n+ : rows 0 .. kip in four bands, a lane's two columns ------
-                    {
-                        // bands of a multiple of four rows; rows past kip meet zc's zero padding
-                        const int band = 4 * ((kip + 4 * BW) / (4 * BW)), r0 = wave * band;
-                        const int r1 = min(r0 + band, (kip + 4) & ~3);
-                        const double *ja = J + c0 * ldj, *jb = J + c1 * ldj;
-                        const double *zk = zc + kip;
-                        double a0 = 0.0, a1 = 0.0;
-                        for (int r = r0; r < r1; r += 4) {
+                    if (!d_valid) {
+                        // ---- d = J' n+ : rows 0 .. kip in four bands, a lane's two columns ------
+                        {
+                            // bands of a multiple of four rows; rows past kip meet zc's zero padding
+                            const int band = 4 * ((kip + 4 * BW) / (4 * BW)), r0 = wave * band;
+                            const int r1 = min(r0 + band, (kip + 4) & ~3);
+                            const double *ja = J + c0 * ldj, *jb = J + c1 * ldj;
+                            const double *zk = zc + kip;
+                            double a0 = 0.0, a1 = 0.0;
+                            for (int r = r0; r < r1; r += 4) {
 #pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                const double nr = zk[-(r + e)];
-                                a0 = fma(ja[r + e], nr, a0);
-                                a1 = fma(jb[r + e], nr, a1);
+                                for (int e = 0; e < 4; e++) {
+                                    const double nr = zk[-(r + e)];
+                                    a0 = fma(ja[r + e], nr, a0);
+                                    a1 = fma(jb[r + e], nr, a1);
+                                }
                             }
+                            dpart[wave * PSTR + i0] = sgn * a0;
+                            dpart[wave * PSTR + i1] = sgn * a1;
                         }
-                        dpart[wave * PSTR + i0] = sgn * a0;
-                        dpart[wave * PSTR + i1] = sgn * a1;
+                        BSTAMP(3);
+                        __syncthreads();
+                        BSTAMP(4);
+                        d0 = ((dpart[i0] + dpart[PSTR + i0]) + dpart[2 * PSTR + i0]) + dpart[3 * PSTR + i0];
+                        d1 = ((dpart[i1] + dpart[PSTR + i1]) + dpart[2 * PSTR + i1]) + dpart[3 * PSTR + i1];
+                        d0 = v0 ? d0 : 0.0;
+                        d1 = v1 ? d1 : 0.0;
+                        d_valid = true;
                     }
-                    BSTAMP(3);
-                    __syncthreads();
-                    BSTAMP(4);
-                    double d0 = ((dpart[i0] + dpart[PSTR + i0]) + dpart[2 * PSTR + i0]) + dpart[3 * PSTR + i0];
-                    double d1 = ((dpart[i1] + dpart[PSTR + i1]) + dpart[2 * PSTR + i1]) + dpart[3 * PSTR + i1];
-                    d0 = v0 ? d0 : 0.0;
-                    d1 = v1 ? d1 : 0.0;
                     dsv[i0] = d0;
                     dsv[i1] = d1;
                     d1s[i0] = i0 < iq ? d0 : 0.0;
@@ -515,10 +535,15 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     double r1v = ((rpart[i1] + rpart[PSTR + i1]) + rpart[2 * PSTR + i1]) + rpart[3 * PSTR + i1];
                     r0v = i0 < iq ? r0v : 0.0;
                     r1v = i1 < iq ? r1v : 0.0;
-                    const double np0 = (v0 && i0 <= kip) ? sgn * zc[kip - min(i0, kip)] : 0.0;
-                    const double np1 = (v1 && i1 <= kip) ? sgn * zc[kip - min(i1, kip)] : 0.0;
-                    const double zz = wave_sum((v0 ? z0 * z0 : 0.0) + (v1 ? z1 * z1 : 0.0));
-                    const double zn = wave_sum((v0 ? z0 * np0 : 0.0) + (v1 ? z1 * np1 : 0.0));
+                    // z . n+ = ||d2||^2 (z = J2 d2 and J2' n+ = d2), and for the box problem, whose
+                    // Hessian is weight_R I, z . z = ||d2||^2 / weight_R: both come from the suffix
+                    // sums of d^2, which an addition needs anyway (accumulated from the far end like
+                    // the reference's chain of hypots; a total minus a prefix would cancel)
+                    const double e0 = (i0 >= iq && v0) ? d0 * d0 : 0.0, e1 = (i1 >= iq && v1) ? d1 * d1 : 0.0;
+                    const double S1 = wave_suffix_scan(e1, lane);
+                    const double S0 = wave_suffix_scan(e0, lane) + bcast(S1, 0);
+                    const double zn = bcast(iq >= HALF ? S1 : S0, iq & 63);
+                    const double zz = zn * inv_weight_R;
                     // step 2b: t1 = min u_k / r_k over r_k > 0, lowest position on ties (:322-334)
                     double t1 = (i0 < iq && r0v > 0.0) ? u0 / r0v : DINF;
                     int kpos = i0, aux2 = 0;
@@ -543,7 +568,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                         u0 -= t * r0v;
                         u1 -= t * r1v;
                         ucand += t;
-                        drop_constraint(kpos);
+                        drop_constraint(kpos, d0, d1);
                         BSTAMP(10);
                         continue;
                     }
@@ -558,13 +583,8 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     ucand += t;
                     if (t == t2) { // full step: add the constraint (:392-426, add_constraint :450-513)
                         falg += 6.0 * nn * (nn - iq - 1);
-                        // suffix norms nu_j = ||d[j .. jt]||, accumulated from the far end like the
-                        // reference's chain of hypots (a total minus a prefix would cancel)
-                        const double e0 = (i0 >= iq && v0) ? d0 * d0 : 0.0, e1 = (i1 >= iq && v1) ? d1 * d1 : 0.0;
-                        const double sc1 = wave_scan(lane_reverse(e1, lane));
-                        const double sc0 = wave_scan(lane_reverse(e0, lane)) + lane63(sc1);
-                        // norm and reciprocal norm from one rsqrt chain: no division in the coefficients
-                        const double S0 = lane_reverse(sc0, lane), S1 = lane_reverse(sc1, lane);
+                        // suffix norms nu_j = ||d[j .. jt]|| and their reciprocals from one rsqrt chain:
+                        // no division in the coefficients
                         double nu0 = 0.0, inu0 = 0.0, nu1 = 0.0, inu1 = 0.0;
                         if (S0 > 0.0) sqrt_rsqrt(S0, nu0, inu0);
                         if (S1 > 0.0) sqrt_rsqrt(S1, nu1, inu1);
@@ -690,7 +710,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                         break; // goto l1 (its barrier publishes J and T)
                     }
                     // partial step (:434-446): drop the blocking constraint, re-evaluate row ip
-                    drop_constraint(kpos);
+                    drop_constraint(kpos, d0, d1);
                     BSTAMP(10);
                     {
                         const double t0 = zc[kip - min(i0, kip)], t1b = zc[kip - min(i1, kip)];

@@ -31,6 +31,10 @@ namespace mpcb {
 namespace {
 
 constexpr int QL = 32;                   // capacity of the LDS-resident factor
+// Box problems hand over earlier: their dense second stage is LDS-resident and fast, and the
+// instances that fill the factor there are the numerically infeasible ones, which run to ~100
+// active rows whatever the capacity -- every iteration they spend here is repeated there.
+constexpr int QL_BOX = 24;
 constexpr int TRI = QL * (QL + 1) / 2;   // packed upper triangle, column-major
 constexpr int LDI = QL + 1;
 
@@ -769,7 +773,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 if (lane < iq) W.wsU[lane] = ua - t * ra;
                 ucand = ufirst(ucand + t);
                 if (t == t2) { // full step: add the constraint (:392-426, add_constraint :450-513)
-                    if (iq >= QL) {
+                    if (iq >= (POLY ? QL : QL_BOX)) {
                         status = STATUS_UNRESOLVED;
                         done = true;
                         break;
