@@ -222,9 +222,13 @@ class DecoupledWorkload:
         # X axis' second-stage kernel, one workgroup per CU, leaves idle)
         self.pl = P.BatchedPlanner(self.N, formulation=P.BOX_1D, weight_R=1.0, device=dev)
         self.pl_y = P.BatchedPlanner(self.N, formulation=P.BOX_1D, weight_R=1.0, device=dev)
-        self.side = torch.cuda.Stream(device=dev)
+        # the X axis carries the long second stage, so it gets the high-priority stream: its first
+        # stage is dispatched ahead of the Y axis' instead of sharing the CUs with it
+        self.hi = torch.cuda.Stream(device=dev, priority=-1)
+        self.side = torch.cuda.Stream(device=dev, priority=0)
         self.ev_fork = torch.cuda.Event()
         self.ev_join = torch.cuda.Event()
+        self.ev_join_x = torch.cuda.Event()
         i = self.inputs
         self.px = self.pl.prepare_box(i["x0"], i["xmin"], i["xmax"])
         self.py = self.pl_y.prepare_box(i["y0"], i["ymin"], i["ymax"])
@@ -237,10 +241,13 @@ class DecoupledWorkload:
     def step(self):
         main = torch.cuda.current_stream()
         self.ev_fork.record(main)
+        self.hi.wait_event(self.ev_fork)
         self.side.wait_event(self.ev_fork)
-        self.pl.solve_box_prepared(self.px, out=self.outx, stream=main)
+        self.pl.solve_box_prepared(self.px, out=self.outx, stream=self.hi)
         self.pl_y.solve_box_prepared(self.py, out=self.outy, stream=self.side)
+        self.ev_join_x.record(self.hi)
         self.ev_join.record(self.side)
+        main.wait_event(self.ev_join_x)
         main.wait_event(self.ev_join)
 
     def results(self):
