@@ -64,7 +64,7 @@ def main():
 
 
 def short(name):
-    name = name.replace("void mpcb::(anonymous namespace)::", "")
+    name = name.replace("void ", "", 1).replace("mpcb::(anonymous namespace)::", "")
     return name.split("(")[0]
 
 
