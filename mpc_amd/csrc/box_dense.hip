@@ -35,6 +35,8 @@
 // barrier per reduction and serialised on one wave's back substitution.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "device_common.h"
 #include "kernels.h"
 
@@ -306,36 +308,48 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     double qa = 0.0, qb = 0.0;
                     const int na = i0 > qq ? i0 - 1 : i0, nb = i1 > qq ? i1 - 1 : i1;
                     const bool wa = i0 != qq && i0 <= last, wb = i1 != qq && i1 <= last;
-                    for (int jb = qq; jb < last; jb += 4) {
-                        double cna[4], cnb[4], gv[4], av[4], bv4[4];
+                    // (the lanes' second rows exist only once the working set is beyond 64 rows)
+                    auto chain = [&](auto two) {
+                        constexpr bool TWO = decltype(two)::value;
+                        for (int jb = qq; jb < last; jb += 4) {
+                            double cna[4], cnb[4], gv[4], av[4], bv4[4];
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const int j = min(jb + e, last - 1);
-                            const int cbase = (j + 1) * (j + 2) / 2;
-                            const double ta = Tp[cbase + min(i0, j + 1)], tb = Tp[cbase + min(i1, j + 1)];
-                            cna[e] = (i0 <= j + 1) ? ta : 0.0;
-                            cnb[e] = (i1 <= j + 1) ? tb : 0.0;
-                            gv[e] = gs[j];
-                            av[e] = ca[j];
-                            bv4[e] = cb[j];
-                        }
-                        wsync(); // every lane has read columns jb + 1 .. jb + 4 before columns jb .. are overwritten
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const int j = jb + e;
-                            if (j < last) {
-                                qa = fma(gv[e], cja, qa);
-                                qb = fma(gv[e], cjb, qb);
-                                const double oa = fma(av[e], qa, bv4[e] * cna[e]), ob = fma(av[e], qb, bv4[e] * cnb[e]);
-                                cja = cna[e];
-                                cjb = cnb[e];
-                                const int obase = j * (j + 1) / 2;
-                                if (wa && na <= j) Tp[obase + na] = oa;
-                                if (wb && nb <= j) Tp[obase + nb] = ob;
+                            for (int e = 0; e < 4; e++) {
+                                const int j = min(jb + e, last - 1);
+                                const int cbase = (j + 1) * (j + 2) / 2;
+                                const double ta = Tp[cbase + min(i0, j + 1)];
+                                cna[e] = (i0 <= j + 1) ? ta : 0.0;
+                                if constexpr (TWO) {
+                                    const double tb = Tp[cbase + min(i1, j + 1)];
+                                    cnb[e] = (i1 <= j + 1) ? tb : 0.0;
+                                }
+                                gv[e] = gs[j];
+                                av[e] = ca[j];
+                                bv4[e] = cb[j];
                             }
+                            wsync(); // every lane has read columns jb + 1 .. jb + 4 before columns jb .. are overwritten
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int j = jb + e;
+                                if (j < last) {
+                                    const int obase = j * (j + 1) / 2;
+                                    qa = fma(gv[e], cja, qa);
+                                    const double oa = fma(av[e], qa, bv4[e] * cna[e]);
+                                    cja = cna[e];
+                                    if (wa && na <= j) Tp[obase + na] = oa;
+                                    if constexpr (TWO) {
+                                        qb = fma(gv[e], cjb, qb);
+                                        const double ob = fma(av[e], qb, bv4[e] * cnb[e]);
+                                        cjb = cnb[e];
+                                        if (wb && nb <= j) Tp[obase + nb] = ob;
+                                    }
+                                }
+                            }
+                            wsync();
                         }
-                        wsync();
-                    }
+                    };
+                    if (last >= HALF) chain(std::true_type{});
+                    else chain(std::false_type{});
                 }
             }
             // working-set arrays: positions above qq move down by one (registers, every wave)
