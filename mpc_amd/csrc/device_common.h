@@ -103,8 +103,9 @@ __device__ __forceinline__ int wave_min(int v) {
 }
 
 // Minimum of (val, key) over the wave; the smaller key wins ties; aux travels with the
-// winner.  Results are wave-uniform.  A lane without a candidate passes val = +inf.
-__device__ __forceinline__ void wave_argmin(double &val, int &key, int &aux) {
+// winner.  Results are wave-uniform; returns the winning lane (0 if no lane has a candidate).
+// A lane without a candidate passes val = +inf.
+__device__ __forceinline__ int wave_argmin(double &val, int &key, int &aux) {
     const double m = wave_min(val);
     const bool cand = val == m;
     const int k = wave_min(cand ? key : 0x7fffffff);
@@ -113,6 +114,7 @@ __device__ __forceinline__ void wave_argmin(double &val, int &key, int &aux) {
     aux = __builtin_amdgcn_readlane(aux, src);
     val = m;
     key = k;
+    return src;
 }
 
 // s = sqrt(x) and is = 1/sqrt(x) for x > 0 from ONE dependent chain (hardware reciprocal

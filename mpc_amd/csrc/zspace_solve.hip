@@ -196,13 +196,32 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     double *cref = tab + (POLY ? (sd.nphase + 1) * 12 : 0);              // [phase][x,y] ZMP reference
 
     // ---- owned knots ------------------------------------------------------
-    int kn[NPL], kc[NPL];
+    // Lane l owns knots l + 64 c.  Only what the main loop reads stays in registers for the
+    // whole solve (kcb, the packed phase/row below); the knot numbers themselves are
+    // recomputed where the prologue, the rare paths and the epilogue need them.
+    int lane_k = lane; // (laundered after the main loop: nothing derived from it stays live across it)
+    auto KN = [&](int c) -> int { return lane_k + 64 * c; };
+    auto KC = [&](int c) -> int { return KN(c) < N ? KN(c) : N - 1; };
+    unsigned kcb[NPL];   // byte offset of the (clamped) knot inside a table row
     unsigned validm = 0; // bit (c*4+e): the slot exists
 #pragma unroll
-    for (int c = 0; c < NPL; c++) {
-        kn[c] = lane + 64 * c;
-        kc[c] = kn[c] < N ? kn[c] : N - 1;
-    }
+    for (int c = 0; c < NPL; c++) kcb[c] = (unsigned)KC(c) * 8u;
+    // Entries of the N x N response tables are fetched by buffer loads: the table is a buffer
+    // resource (four scalar registers), the wave-uniform part of the offset (a row, or a column)
+    // rides in a scalar register and the lane adds a 32-bit byte offset -- no per-lane 64-bit
+    // address arithmetic.  (An offset past the table would read 0; none is generated.)
+    const unsigned tab_bytes = (unsigned)N * (unsigned)N * 8u;
+    auto table = [&](const double *t) -> __amdgpu_buffer_rsrc_t {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(t), 0, tab_bytes, 0x00020000);
+    };
+    auto tab_ld = [](__amdgpu_buffer_rsrc_t t, unsigned uniform_bytes, unsigned lane_bytes) -> double {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(t, lane_bytes, uniform_bytes, 0);
+        return __hiloint2double((int)v.y, (int)v.x);
+    };
+    const unsigned rowB = (unsigned)N * 8u; // bytes of a table row
+    const __amdgpu_buffer_rsrc_t tS = table(HV ? sd.Spp : sd.S), tW = table(HV ? sd.Wtp : sd.Wt);
+    const __amdgpu_buffer_rsrc_t tS1 = table(sd.Sps), tS2 = table(sd.Saa), tW1 = table(sd.Wta); // HV only
 
     // ---- instance inputs ---------------------------------------------------
     // Every scalar input of the instance is fetched by ONE vector load (a lane per value) and
@@ -258,24 +277,32 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
         ch2 = ufirst(ch * ch);
     }
     // entries of the response tables at a flat offset (row * N + column)
-    auto S_at = [&](size_t off) -> double {
-        if constexpr (HV) return fma(ch2, sd.Saa[off], fma(-ch, sd.Sps[off], sd.Spp[off]));
-        else return sd.S[off];
+    // S[row][col] with a wave-uniform col and a per-lane row, and W^T[row][.] at the lane's
+    // byte offset with a wave-uniform row: uniform part in scalar registers, 32-bit lane part
+    auto S_col = [&](int row, int col) -> double {
+        const unsigned bo = (unsigned)row * rowB, uo = (unsigned)col * 8u;
+        if constexpr (HV) return fma(ch2, tab_ld(tS2, uo, bo), fma(-ch, tab_ld(tS1, uo, bo), tab_ld(tS, uo, bo)));
+        else return tab_ld(tS, uo, bo);
     };
-    auto Wt_at = [&](size_t off) -> double {
-        if constexpr (HV) return fma(-ch, sd.Wta[off], sd.Wtp[off]);
-        else return sd.Wt[off];
+    auto Wt_row = [&](int row, unsigned byte_off) -> double {
+        const unsigned ro = (unsigned)row * rowB;
+        if constexpr (HV) return fma(-ch, tab_ld(tW1, ro, byte_off), tab_ld(tW, ro, byte_off));
+        else return tab_ld(tW, ro, byte_off);
     };
 
     // ---- constraint rows ---------------------------------------------------
-    int ph[NPL], row0[NPL];
+    // phr[c]: phase (10 bits; < 1024) | first row << 10 of knot c; tabo[c]: where the phase's
+    // (p, q, r) triples start in tab
+    int phr[NPL], tabo[NPL];
     double lo[NPL], hi[NPL];
 #pragma unroll
     for (int c = 0; c < NPL; c++) {
-        ph[c] = 0;
-        row0[c] = kn[c];
+        phr[c] = KN(c) << 10;
+        tabo[c] = 0;
         lo[c] = hi[c] = 0.0;
     }
+    auto PH = [&](int c) -> int { return phr[c] & 1023; };
+    auto ROW0 = [&](int c) -> int { return phr[c] >> 10; };
     if constexpr (POLY) {
         // computeSteps + buildPolygonMatrix: lane l builds the polygon of phase l
         if constexpr (!ROWS)
@@ -298,26 +325,29 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
         }
         // (all loads first, from clamped -- always valid -- knots: conditional loads would be
         // issued and waited for one chunk after the other)
+        int ph[NPL], row0[NPL];
 #pragma unroll
         for (int c = 0; c < NPL; c++) {
-            ph[c] = sd.knot_phase[kc[c]];
-            row0[c] = sd.knot_row0[kc[c]];
+            ph[c] = sd.knot_phase[KC(c)];
+            row0[c] = sd.knot_row0[KC(c)];
         }
 #pragma unroll
         for (int c = 0; c < NPL; c++) {
-            if (kn[c] < N) {
+            if (KN(c) < N) {
                 const int E = ((ph[c] & 1) && ph[c] < 2 * sd.steps) ? 3 : 4;
                 validm |= ((1u << E) - 1u) << (4 * c);
             } else if (!ROWS) {
                 ph[c] = sd.nphase;
             }
+            phr[c] = ph[c] | (row0[c] << 10);
+            tabo[c] = ph[c] * 12;
         }
     } else {
 #pragma unroll
         for (int c = 0; c < NPL; c++) {
-            if (kn[c] < N) {
-                lo[c] = in.zmin[(size_t)inst * N + kn[c]];
-                hi[c] = in.zmax[(size_t)inst * N + kn[c]];
+            if (KN(c) < N) {
+                lo[c] = in.zmin[(size_t)inst * N + KN(c)];
+                hi[c] = in.zmax[(size_t)inst * N + KN(c)];
                 validm |= 3u << (4 * c);
             } else { // rows past the horizon evaluate to +inf
                 lo[c] = -DINF;
@@ -337,26 +367,26 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     auto accum_group = [&](auto wtag, int a0, double *vx, double *vy, auto gtag) {
         constexpr int WH = decltype(wtag)::value;
         constexpr int G = decltype(gtag)::value;
-        const double *T0 = WH == 0 ? (HV ? sd.Spp : sd.S) : (HV ? sd.Wtp : sd.Wt);
-        size_t off[G];
+        const __amdgpu_buffer_rsrc_t T0 = WH == 0 ? tS : tW;
+        unsigned off[G];
         double ca[G], cb[G], sv[G][NPL];
 #pragma unroll
         for (int j = 0; j < G; j++) {
-            off[j] = (size_t)(ufirst(W.wsKS[a0 + j]) >> 2) * N;
+            off[j] = (unsigned)(ufirst(W.wsKS[a0 + j]) >> 2) * rowB;
             ca[j] = W.cx[a0 + j];
             cb[j] = W.cy[a0 + j];
         }
 #pragma unroll
         for (int j = 0; j < G; j++)
 #pragma unroll
-            for (int c = 0; c < NPL; c++) sv[j][c] = T0[off[j] + kc[c]];
+            for (int c = 0; c < NPL; c++) sv[j][c] = tab_ld(T0, off[j], kcb[c]);
         if constexpr (HV) {
-            const double *T1 = WH == 0 ? sd.Sps : sd.Wta;
+            const __amdgpu_buffer_rsrc_t T1 = WH == 0 ? tS1 : tW1;
             double s1[G][NPL];
 #pragma unroll
             for (int j = 0; j < G; j++)
 #pragma unroll
-                for (int c = 0; c < NPL; c++) s1[j][c] = T1[off[j] + kc[c]];
+                for (int c = 0; c < NPL; c++) s1[j][c] = tab_ld(T1, off[j], kcb[c]);
 #pragma unroll
             for (int j = 0; j < G; j++)
 #pragma unroll
@@ -365,7 +395,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
 #pragma unroll
                 for (int j = 0; j < G; j++)
 #pragma unroll
-                    for (int c = 0; c < NPL; c++) s1[j][c] = sd.Saa[off[j] + kc[c]];
+                    for (int c = 0; c < NPL; c++) s1[j][c] = tab_ld(tS2, off[j], kcb[c]);
 #pragma unroll
                 for (int j = 0; j < G; j++)
 #pragma unroll
@@ -401,7 +431,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 cxr[j] = p0 + j < P ? cref[2 * p2] : 0.0;
                 cyr[j] = p0 + j < P ? cref[2 * p2 + 1] : 0.0;
 #pragma unroll
-                for (int c = 0; c < NPL; c++) mv[j][c] = Mp[(size_t)p2 * N + kc[c]];
+                for (int c = 0; c < NPL; c++) mv[j][c] = Mp[(size_t)p2 * N + KC(c)];
             }
 #pragma unroll
             for (int j = 0; j < 8; j++)
@@ -426,22 +456,22 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     // not exist; clamp so the (masked) read stays inside the instance's rows
     const double *rows = ROWS ? in.rows_pqr + (size_t)inst * sd.m * 3 : nullptr;
     auto rowIdx = [&](int c, int e) -> int {
-        const int r = row0[c] + e;
+        const int r = ROW0(c) + e;
         return r < sd.m ? r : sd.m - 1;
     };
     auto slotP = [&](int c, int e) -> double {
         if constexpr (ROWS) return rows[rowIdx(c, e) * 3];
-        else if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3];
+        else if constexpr (POLY) return tab[tabo[c] + e * 3];
         else return e == 0 ? 1.0 : -1.0;
     };
     auto slotQ = [&](int c, int e) -> double {
         if constexpr (ROWS) return rows[rowIdx(c, e) * 3 + 1];
-        else if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3 + 1];
+        else if constexpr (POLY) return tab[tabo[c] + e * 3 + 1];
         else return 0.0;
     };
     auto slotR = [&](int c, int e) -> double {
         if constexpr (ROWS) return rows[rowIdx(c, e) * 3 + 2];
-        else if constexpr (POLY) return tab[(ph[c] * 4 + e) * 3 + 2];
+        else if constexpr (POLY) return tab[tabo[c] + e * 3 + 2];
         else return e == 0 ? -lo[c] : hi[c];
     };
 
@@ -453,8 +483,8 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
         double kz[4];
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-            if constexpr (HV) kz[a] = fma(-ch, sd.Kza[(size_t)kc[c] * 4 + a], sd.Kzp[(size_t)kc[c] * 4 + a]);
-            else kz[a] = sd.Kz[(size_t)kc[c] * 4 + a];
+            if constexpr (HV) kz[a] = fma(-ch, sd.Kza[(size_t)KC(c) * 4 + a], sd.Kzp[(size_t)KC(c) * 4 + a]);
+            else kz[a] = sd.Kz[(size_t)KC(c) * 4 + a];
         }
         zxu[c] = kz[0] * wx[0] + kz[1] * wx[1] + kz[2] * wx[2] + kz[3] * wx[3];
         zyu[c] = kz[0] * wy[0] + kz[1] * wy[1] + kz[2] * wy[2] + kz[3] * wy[3];
@@ -496,9 +526,8 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     double zx[NPL], zy[NPL];
     bool pending = false;       // a candidate's partial steps are part of x (cap exit)
     bool zmp_current = false;   // zx, zy hold the ZMP of the final multipliers
-    int ipRow = 0, ipKS = 0;
+    int ipRow = 0, ipKS = 0, ipPh = 0;
     double pip = 0.0, qip = 0.0, ucand = 0.0, s_ip = 0.0;
-
     STAMP(0);
     for (;;) { // step 1 (l1)
         iters++;
@@ -584,8 +613,11 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
             // then the lowest row attaining it (rows ascend with (knot, edge) for the polygon
             // rows and with (side, knot) for the box rows).  If that row is in the working set
             // -- its value is a rounding residue -- the masked search below decides instead.
+            // The winner's phase and first row come from the registers of the lane that owns
+            // its knot (one readlane each) rather than from the per-knot tables in memory: a
+            // dependent round trip to L2 per candidate would sit on the critical path.
             double bv = DINF;
-            int brow = 0x7fffffff, bks = 0;
+            int brow = 0x7fffffff, bks = 0, bph = 0, brow0 = 0;
             bool masked = restart_seen;
             if (!masked) {
                 const double mw = wave_min(mloc);
@@ -598,6 +630,19 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                     const int src = __ffsll((long long)win) - 1;
                     const int act = __builtin_amdgcn_readlane((int)((actm >> (slot & 31)) & 1u), src);
                     bks = __builtin_amdgcn_readlane(ks, src);
+                    if constexpr (POLY) {
+                        // which of the winner lane's knots: a wave-uniform choice among
+                        // readlanes (a per-lane choice would be an indexed register array)
+                        const int cs = bks >> 8;
+                        int pr = __builtin_amdgcn_readlane(phr[0], src);
+#pragma unroll
+                        for (int c = 1; c < NPL; c++) {
+                            const int t = __builtin_amdgcn_readlane(phr[c], src);
+                            pr = cs == c ? t : pr;
+                        }
+                        bph = pr & 1023;
+                        brow0 = pr >> 10;
+                    }
                     brow = kmin;
                     bv = mw;
                     masked = act != 0;
@@ -609,6 +654,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 bv = DINF;
                 brow = 0x7fffffff;
                 bks = 0;
+                int lph = 0, lrow0 = 0;
 #pragma unroll
                 for (int c = 0; c < NPL; c++)
 #pragma unroll
@@ -616,22 +662,27 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                         const unsigned bit = 1u << (4 * c + e);
                         if ((validm & bit) && !(actm & bit) && (exclm & bit)) {
                             const double v = fma(slotP(c, e), zx[c], fma(slotQ(c, e), zy[c], slotR(c, e)));
-                            const int ks = (kn[c] << 2) | e;
-                            const int row = POLY ? ks : kn[c] + e * N;
+                            const int ks = (KN(c) << 2) | e;
+                            const int row = POLY ? ks : KN(c) + e * N;
                             if (v < ssv && (v < bv || (v == bv && row < brow))) {
                                 bv = v;
                                 brow = row;
                                 bks = ks;
+                                lph = PH(c);
+                                lrow0 = ROW0(c);
                             }
                         }
                     }
-                wave_argmin(bv, brow, bks);
+                const int src = wave_argmin(bv, brow, bks);
+                bph = __builtin_amdgcn_readlane(lph, src);
+                brow0 = __builtin_amdgcn_readlane(lrow0, src);
             }
             STAMP(3);
             if (bv < ssv) {
                 ssv = bv;
                 ipKS = bks;
-                ipRow = POLY ? ufirst(sd.knot_row0[bks >> 2]) + (bks & 3) : brow;
+                ipPh = bph;
+                ipRow = POLY ? brow0 + (bks & 3) : brow;
                 s_ip = bv;
             }
             if (ssv >= 0.0) {
@@ -644,9 +695,8 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 pip = ufirst(rows[ipRow * 3]);
                 qip = ufirst(rows[ipRow * 3 + 1]);
             } else if constexpr (POLY) {
-                const int php = sd.knot_phase[kip];
-                pip = ufirst(tab[(php * 4 + eip) * 3]);
-                qip = ufirst(tab[(php * 4 + eip) * 3 + 1]);
+                pip = ufirst(tab[(ipPh * 4 + eip) * 3]);
+                qip = ufirst(tab[(ipPh * 4 + eip) * 3 + 1]);
             } else {
                 pip = eip == 0 ? 1.0 : -1.0;
                 qip = 0.0;
@@ -655,7 +705,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
             pending = true;
             // n_ip' G^-1 n_ip; the load is consumed after the gather of the first pass has been
             // issued, so that the two memory round trips overlap
-            const double skk = S_at((size_t)kip * N + kip);
+            const double skk = S_col(kip, kip);
             // g_a = n_a' G^-1 n_ip depends on the pair (a, ip) only: it is gathered once per
             // candidate, and a drop merely closes the gap (lanes above the dropped position move
             // down by one) instead of paying another round trip to the table
@@ -675,7 +725,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 if (lane < iq) {
                     if (!have_g) {
                         const int ka = W.wsKS[lane] >> 2;
-                        ga = (W.wsP[lane] * pip + W.wsQ[lane] * qip) * S_at((size_t)ka * N + kip);
+                        ga = (W.wsP[lane] * pip + W.wsQ[lane] * qip) * S_col(ka, kip);
                     }
                     ua = W.wsU[lane];
                 }
@@ -724,14 +774,14 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                     double zvx[NPL], zvy[NPL];
 #pragma unroll
                     for (int c = 0; c < NPL; c++) {
-                        const double w = Wt_at((size_t)kip * N + kc[c]);
+                        const double w = Wt_row(kip, kcb[c]);
                         zvx[c] = pip * w;
                         zvy[c] = qip * w;
                     }
                     accum_rows(TAB_W, iq, zvx, zvy);
 #pragma unroll
                     for (int c = 0; c < NPL; c++)
-                        if (kn[c] < N) acc += zvx[c] * zvx[c] + zvy[c] * zvy[c];
+                        if (KN(c) < N) acc += zvx[c] * zvx[c] + zvy[c] * zvy[c];
                     znz = fabs(wave_sum(acc)) > EPS;
                     wsync();
                 }
@@ -861,6 +911,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     STAMP(7);
 
     // ---- outputs -------------------------------------------------------------
+    asm volatile("" : "+v"(lane_k));
     const bool solved = status == MPCB_OK || status == MPCB_ITER_CAP;
     if (status == STATUS_UNRESOLVED && lane == 0 && unresolved_list)
         unresolved_list[atomicAdd(unresolved_count, 1)] = inst; // re-solved by the dense kernel
@@ -894,9 +945,9 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     auto store_pair = [&](double *ox, double *oy, const double *vx, const double *vy) {
 #pragma unroll
         for (int c = 0; c < NPL; c++)
-            if (kn[c] < N) {
-                if (ox) ox[(size_t)inst * N + kn[c]] = solved ? vx[c] : 0.0;
-                if (oy) oy[(size_t)inst * N + kn[c]] = solved ? vy[c] : 0.0;
+            if (KN(c) < N) {
+                if (ox) ox[(size_t)inst * N + KN(c)] = solved ? vx[c] : 0.0;
+                if (oy) oy[(size_t)inst * N + KN(c)] = solved ? vy[c] : 0.0;
             }
     };
     STAMP(12);
@@ -906,7 +957,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
         double jx[NPL], jy[NPL];
 #pragma unroll
         for (int c = 0; c < NPL; c++) {
-            const double *k4 = sd.Kx + (size_t)kc[c] * 4;
+            const double *k4 = sd.Kx + (size_t)KC(c) * 4;
             jx[c] = k4[0] * wx[0] + k4[1] * wx[1] + k4[2] * wx[2] + k4[3] * wx[3];
             jy[c] = k4[0] * wy[0] + k4[1] * wy[1] + k4[2] * wy[2] + k4[3] * wy[3];
         }
@@ -1012,9 +1063,9 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
         }
 #pragma unroll
         for (int c = 0; c < NPL; c++)
-            if (kn[c] < N) {
-                if (out.zmp_x) out.zmp_x[(size_t)inst * N + kn[c]] = solved ? zx[c] : 0.0;
-                if (out.zmp_y) out.zmp_y[(size_t)inst * N + kn[c]] = solved ? zy[c] : 0.0;
+            if (KN(c) < N) {
+                if (out.zmp_x) out.zmp_x[(size_t)inst * N + KN(c)] = solved ? zx[c] : 0.0;
+                if (out.zmp_y) out.zmp_y[(size_t)inst * N + KN(c)] = solved ? zy[c] : 0.0;
                 if (out.min_margin) {
                     // getConstraintViolation (MPCPlanner.cpp:1132-1153)
                     double mn = DINF;
@@ -1022,7 +1073,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                     for (int e = 0; e < ES; e++)
                         if (validm & (1u << (4 * c + e)))
                             mn = fmin(mn, slotP(c, e) * zx[c] + slotQ(c, e) * zy[c] + slotR(c, e));
-                    out.min_margin[(size_t)inst * N + kn[c]] = solved ? mn : 0.0;
+                    out.min_margin[(size_t)inst * N + KN(c)] = solved ? mn : 0.0;
                 }
             }
     }
