@@ -102,6 +102,25 @@ __device__ __forceinline__ int wave_min(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Sum of a and minimum of b over the wave in one pass: the two dependent chains interleave,
+// so each fills the other's issue gaps.  Results are wave-uniform.
+__device__ __forceinline__ void wave_sum_min(double a, double b, double &sum, double &mn) {
+    a += dpp_perm_f64<0xB1>(a);
+    b = fmin(b, dpp_perm_f64<0xB1>(b));
+    a += dpp_perm_f64<0x4E>(a);
+    b = fmin(b, dpp_perm_f64<0x4E>(b));
+    a += dpp_perm_f64<0x141>(a);
+    b = fmin(b, dpp_perm_f64<0x141>(b));
+    a += dpp_perm_f64<0x140>(a);
+    b = fmin(b, dpp_perm_f64<0x140>(b));
+    a += dpp_f64<0x142, 0xA>(0.0, a);
+    b = fmin(b, dpp_f64<0x142, 0xA>(DINF, b));
+    a += dpp_f64<0x143, 0xC>(0.0, a);
+    b = fmin(b, dpp_f64<0x143, 0xC>(DINF, b));
+    sum = lane63(a);
+    mn = lane63(b);
+}
+
 // Minimum of (val, key) over the wave; the smaller key wins ties; aux travels with the
 // winner.  Results are wave-uniform; returns the winning lane (0 if no lane has a candidate).
 // A lane without a candidate passes val = +inf.

@@ -46,13 +46,12 @@ struct WaveState {
     double Rinv[QL * LDI];
     double wsU[QL + 1], wsP[QL + 1], wsQ[QL + 1];       // working set: multiplier, p, q
     double oldU[QL + 1];                                // copy taken at step 1 (eiquadprog.hpp:275-277)
-    double g[QL + 1], d[QL + 1];
     double cx[QL + 4], cy[QL + 4];                      // row coefficients, zero-padded to a multiple of 4
     int wsRow[QL + 1], wsKS[QL + 4];                    // constraint row; (knot << 2) | slot
     int oldRow[QL + 1], oldKS[QL + 1];
     int pad[3];
 };
-static_assert(QL <= 64, "one lane per working-set position");
+static_assert(QL <= 64 && QL % 4 == 0, "one lane per working-set position; products run four terms per trip");
 static_assert(sizeof(WaveState) % 8 == 0, "tab must stay 8-byte aligned");
 
 __device__ __forceinline__ int tri(int col) { return col * (col + 1) / 2; }
@@ -364,7 +363,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     // whole group of rows (eight while more than four remain, else four) are in flight
     // together; cx/cy are zero beyond n, so the padding rows add 0.
     // (wtag: 0 = the ZMP response S, 1 = the jerk response W^T)
-    auto accum_group = [&](auto wtag, int a0, double *vx, double *vy, auto gtag) {
+    auto accum_group = [&](auto wtag, int a0, int ksv, double *vx, double *vy, auto gtag) {
         constexpr int WH = decltype(wtag)::value;
         constexpr int G = decltype(gtag)::value;
         const __amdgpu_buffer_rsrc_t T0 = WH == 0 ? tS : tW;
@@ -372,7 +371,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
         double ca[G], cb[G], sv[G][NPL];
 #pragma unroll
         for (int j = 0; j < G; j++) {
-            off[j] = (unsigned)(ufirst(W.wsKS[a0 + j]) >> 2) * rowB;
+            off[j] = (unsigned)(__builtin_amdgcn_readlane(ksv, a0 + j) >> 2) * rowB;
             ca[j] = W.cx[a0 + j];
             cb[j] = W.cy[a0 + j];
         }
@@ -410,12 +409,15 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 if constexpr (POLY) vy[c] += cb[j] * sv[j][c];
             }
     };
-    auto accum_rows = [&](auto wtag, int n, double *vx, double *vy) {
+    // (The knots of all positions come from ONE LDS read, a lane per position, and are handed
+    // to the scalar unit by readlane: position by position each read was a round trip of its own.)
+    auto ws_knots = [&]() -> int { return W.wsKS[lane < QL + 4 ? lane : 0]; };
+    auto accum_rows = [&](auto wtag, int n, int ksv, double *vx, double *vy) {
         int a0 = 0;
         if constexpr (NPL <= 4 && !HV) {
-            for (; n - a0 > 4; a0 += 8) accum_group(wtag, a0, vx, vy, std::integral_constant<int, 8>{});
+            for (; n - a0 > 4; a0 += 8) accum_group(wtag, a0, ksv, vx, vy, std::integral_constant<int, 8>{});
         }
-        for (; a0 < n; a0 += 4) accum_group(wtag, a0, vx, vy, std::integral_constant<int, 4>{});
+        for (; a0 < n; a0 += 4) accum_group(wtag, a0, ksv, vx, vy, std::integral_constant<int, 4>{});
     };
     constexpr std::integral_constant<int, 0> TAB_S{};
     constexpr std::integral_constant<int, 1> TAB_W{};
@@ -542,7 +544,8 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
             zx[c] = zxu[c];
             zy[c] = zyu[c];
         }
-        accum_rows(TAB_S, iq, zx, zy);
+        const int ks_top = ws_knots(); // lane a: (knot, slot) of working-set position a, as of step 1
+        accum_rows(TAB_S, iq, ks_top, zx, zy);
         STAMP(1);
         // s(x) for every row (:255-261), fused with the search for the most violated row
         // (step 2, :279-287, first pass: ss = 0).  Row values are not kept: the rare
@@ -592,7 +595,9 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
 #pragma unroll
                 for (int c = 0; c < NPL; c++) visit(c, e, e == 0 ? zx[c] - lo[c] : hi[c] - zx[c]);
         }
-        psi = wave_sum(psi);
+        // sum of the violations and lowest row value in one interleaved pair of reductions
+        double mw_all;
+        wave_sum_min(psi, mloc, psi, mw_all);
         falg += 2 * mm * nn;
         exclm = 0xffffffffu; // iaexcl[i] = true (:257)
         if (fabs(psi) <= psi_thr) { // :267-272
@@ -620,14 +625,21 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
             int brow = 0x7fffffff, bks = 0, bph = 0, brow0 = 0;
             bool masked = restart_seen;
             if (!masked) {
-                const double mw = wave_min(mloc);
+                const double mw = mw_all;
                 if (mw < 0.0) {
                     const int slot = mloc == mw ? mslot : -1;
                     const int ks = ((lane + 64 * (slot >> 2)) << 2) | (slot & 3);
                     const int key = slot < 0 ? 0x7fffffff : POLY ? ks : lane + 64 * (slot >> 2) + (slot & 3) * N;
-                    const int kmin = wave_min(key);
-                    const unsigned long long win = __ballot(key == kmin);
+                    // one lane attains the minimum unless rows tie exactly; only then does the
+                    // lowest row have to be found across lanes
+                    unsigned long long win = __ballot(slot >= 0);
+                    int kmin;
+                    if (__popcll(win) > 1) {
+                        kmin = wave_min(key);
+                        win = __ballot(key == kmin);
+                    }
                     const int src = __ffsll((long long)win) - 1;
+                    kmin = __builtin_amdgcn_readlane(key, src);
                     const int act = __builtin_amdgcn_readlane((int)((actm >> (slot & 31)) & 1u), src);
                     bks = __builtin_amdgcn_readlane(ks, src);
                     if constexpr (POLY) {
@@ -723,41 +735,56 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 // g = N_A' G^-1 n_ip ; d = R^-T g (= J1' n_ip) ; r = R^-1 d
                 double da = 0.0, ra = 0.0, ua = 0.0;
                 if (lane < iq) {
-                    if (!have_g) {
-                        const int ka = W.wsKS[lane] >> 2;
+                    if (!have_g) { // (the working set is still that of step 1: ks_top is current)
+                        const int ka = ks_top >> 2;
                         ga = (W.wsP[lane] * pip + W.wsQ[lane] * qip) * S_col(ka, kip);
                     }
                     ua = W.wsU[lane];
                 }
                 have_g = true;
-                W.g[lane < QL ? lane : QL] = ga;
-                wsync();
                 const double mii = ufirst((pip * pip + qip * qip) * skk);
                 STAMP(4);
                 {
                     // d_i = sum_j Rinv[j][i] g_j, r_i = sum_k Rinv[i][k] d_k: plain sums, the
-                    // zeros of Rinv, g and d take care of the triangle and of lanes >= iq
+                    // zeros of Rinv take care of the triangle and of lanes >= iq.  g_j and d_k are
+                    // handed round by readlane (scalar operands of the FMAs), not through LDS.
                     const int lq = lane < QL ? lane : QL - 1;
                     const double *col = W.Rinv + lq, *rowp = W.Rinv + lq * LDI;
-#pragma unroll 4
-                    for (int j = 0; j < iq; j++) da = fma(col[j * LDI], W.g[j], da);
+                    // (four terms per trip, written out: the trip count is rounded up, the extra
+                    // terms meet zeros of Rinv)
+                    for (int j = 0; j < iq; j += 4) {
+                        double rv[4], gv[4];
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; q4++) {
+                            rv[q4] = col[(j + q4) * LDI];
+                            gv[q4] = lane_bcast(ga, j + q4);
+                        }
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; q4++) da = fma(rv[q4], gv[q4], da);
+                    }
                     da = lane < iq ? da : 0.0;
-                    W.d[lane < QL ? lane : QL] = da;
-                    wsync();
-#pragma unroll 4
-                    for (int k = 0; k < iq; k++) ra = fma(rowp[k], W.d[k], ra);
+                    for (int k = 0; k < iq; k += 4) {
+                        double rv[4], dv[4];
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; q4++) {
+                            rv[q4] = rowp[k + q4];
+                            dv[q4] = lane_bcast(da, k + q4);
+                        }
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; q4++) ra = fma(rv[q4], dv[q4], ra);
+                    }
                     ra = lane < iq ? ra : 0.0;
                 }
                 STAMP(5);
                 const double zn = ufirst(mii - wave_sum(da * da)); // z . n_ip
                 // rho = sqrt(zn) is the new diagonal entry of R if the constraint is added; its
                 // reciprocal also gives the full step length t2 = -s_ip / zn without a division
-                double rho = 0.0, irho = 0.0;
-                if (zn > 0.0) {
-                    sqrt_rsqrt(zn, rho, irho);
-                    rho = ufirst(rho);
-                    irho = ufirst(irho);
-                }
+                // (computed without a branch so that this chain and the division chain of the
+                // step length below are scheduled into each other's gaps)
+                double rho, irho;
+                sqrt_rsqrt(zn > 0.0 ? zn : 1.0, rho, irho);
+                rho = zn > 0.0 ? ufirst(rho) : 0.0;
+                irho = zn > 0.0 ? ufirst(irho) : 0.0;
                 // step 2b: t1 = min u_k / r_k over r_k > 0, first minimum wins (:322-334)
                 double t1 = (lane < iq && ra > 0.0) ? ua / ra : DINF;
                 int apos = lane, dummy = 0;
@@ -778,7 +805,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                         zvx[c] = pip * w;
                         zvy[c] = qip * w;
                     }
-                    accum_rows(TAB_W, iq, zvx, zvy);
+                    accum_rows(TAB_W, iq, ws_knots(), zvx, zvy);
 #pragma unroll
                     for (int c = 0; c < NPL; c++)
                         if (KN(c) < N) acc += zvx[c] * zvx[c] + zvy[c] * zvy[c];
@@ -964,7 +991,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
         if constexpr (POLY) {
             if (sd.Wp) accum_phases(sd.Wp, jx, jy);
         }
-        accum_rows(TAB_W, nresp, jx, jy);
+        accum_rows(TAB_W, nresp, ws_knots(), jx, jy);
         store_pair(out.jerk_x, out.jerk_y, jx, jy);
         STAMP(13);
         if (want_com) {
@@ -1059,7 +1086,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 zx[c] = zxu[c];
                 zy[c] = zyu[c];
             }
-            accum_rows(TAB_S, nresp, zx, zy);
+            accum_rows(TAB_S, nresp, ws_knots(), zx, zy);
         }
 #pragma unroll
         for (int c = 0; c < NPL; c++)
