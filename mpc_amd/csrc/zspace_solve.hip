@@ -667,23 +667,26 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 brow = 0x7fffffff;
                 bks = 0;
                 int lph = 0, lrow0 = 0;
+                // (This search is rare.  Its inputs pass through empty asm statements so that
+                // nothing derived from them counts as loop-invariant: hoisted out of the main
+                // loop, the per-slot masks and keys would sit in registers -- or spill -- for
+                // the whole solve.)
+                unsigned elig = validm & ~actm & exclm;
+                int lk = lane_k;
+                asm volatile("" : "+v"(elig), "+v"(lk));
 #pragma unroll
                 for (int c = 0; c < NPL; c++)
 #pragma unroll
                     for (int e = 0; e < ES; e++) {
-                        const unsigned bit = 1u << (4 * c + e);
-                        if ((validm & bit) && !(actm & bit) && (exclm & bit)) {
-                            const double v = fma(slotP(c, e), zx[c], fma(slotQ(c, e), zy[c], slotR(c, e)));
-                            const int ks = (KN(c) << 2) | e;
-                            const int row = POLY ? ks : KN(c) + e * N;
-                            if (v < ssv && (v < bv || (v == bv && row < brow))) {
-                                bv = v;
-                                brow = row;
-                                bks = ks;
-                                lph = PH(c);
-                                lrow0 = ROW0(c);
-                            }
-                        }
+                        const double v = fma(slotP(c, e), zx[c], fma(slotQ(c, e), zy[c], slotR(c, e)));
+                        const int ks = ((lk + 64 * c) << 2) | e;
+                        const int row = POLY ? ks : lk + 64 * c + e * N;
+                        const bool take = ((elig >> (4 * c + e)) & 1u) && v < ssv && (v < bv || (v == bv && row < brow));
+                        bv = take ? v : bv;
+                        brow = take ? row : brow;
+                        bks = take ? ks : bks;
+                        lph = take ? PH(c) : lph;
+                        lrow0 = take ? ROW0(c) : lrow0;
                     }
                 const int src = wave_argmin(bv, brow, bks);
                 bph = __builtin_amdgcn_readlane(lph, src);
@@ -938,30 +941,34 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     STAMP(7);
 
     // ---- outputs -------------------------------------------------------------
-    asm volatile("" : "+v"(lane_k));
+    // (fresh copies of the lane and instance numbers: nothing derived from them before the
+    // main loop -- 64-bit offsets, mostly -- is kept in registers, or spilled, across it)
+    int inst_e = inst;
+    asm volatile("" : "+v"(lane_k), "+s"(inst_e));
+    const int lane_e = lane_k;
     const bool solved = status == MPCB_OK || status == MPCB_ITER_CAP;
-    if (status == STATUS_UNRESOLVED && lane == 0 && unresolved_list)
-        unresolved_list[atomicAdd(unresolved_count, 1)] = inst; // re-solved by the dense kernel
-    if (lane == 0) {
-        if (out.cost) out.cost[inst] = f;
-        if (out.status) out.status[inst] = status;
-        if (out.iters) out.iters[inst] = iters;
-        if (out.n_active) out.n_active[inst] = iq;
-        if (out.alg_flops) out.alg_flops[inst] = (double)(falg + (POLY ? 2 * mm * nn : 0));
+    if (status == STATUS_UNRESOLVED && lane_e == 0 && unresolved_list)
+        unresolved_list[atomicAdd(unresolved_count, 1)] = inst_e; // re-solved by the dense kernel
+    if (lane_e == 0) {
+        if (out.cost) out.cost[inst_e] = f;
+        if (out.status) out.status[inst_e] = status;
+        if (out.iters) out.iters[inst_e] = iters;
+        if (out.n_active) out.n_active[inst_e] = iq;
+        if (out.alg_flops) out.alg_flops[inst_e] = (double)(falg + (POLY ? 2 * mm * nn : 0));
     }
     if (out.active_idx || out.multipliers) {
-        for (int a = lane; a < out.active_stride; a += 64) {
+        for (int a = lane_e; a < out.active_stride; a += 64) {
             const bool in_set = a < iq && a <= QL;
-            if (out.active_idx) out.active_idx[(size_t)inst * out.active_stride + a] = in_set ? W.wsRow[a] : -1;
-            if (out.multipliers) out.multipliers[(size_t)inst * out.active_stride + a] = in_set ? W.wsU[a] : 0.0;
+            if (out.active_idx) out.active_idx[(size_t)inst_e * out.active_stride + a] = in_set ? W.wsRow[a] : -1;
+            if (out.multipliers) out.multipliers[(size_t)inst_e * out.active_stride + a] = in_set ? W.wsU[a] : 0.0;
         }
     }
     // multipliers -> trajectories through the response matrices
     int nresp = iq;
-    set_coefs(lane < iq ? W.wsU[lane] : 0.0, iq);
+    set_coefs(lane_e < iq ? W.wsU[lane_e] : 0.0, iq);
     if (pending && status == MPCB_ITER_CAP && iq < QL) {
         // partial steps of an unfinished candidate are part of x
-        if (lane == 0) {
+        if (lane_e == 0) {
             W.cx[iq] = ucand * pip;
             W.cy[iq] = ucand * qip;
             W.wsKS[iq] = ipKS;
@@ -973,8 +980,8 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
 #pragma unroll
         for (int c = 0; c < NPL; c++)
             if (KN(c) < N) {
-                if (ox) ox[(size_t)inst * N + KN(c)] = solved ? vx[c] : 0.0;
-                if (oy) oy[(size_t)inst * N + KN(c)] = solved ? vy[c] : 0.0;
+                if (ox) ox[(size_t)inst_e * N + KN(c)] = solved ? vx[c] : 0.0;
+                if (oy) oy[(size_t)inst_e * N + KN(c)] = solved ? vy[c] : 0.0;
             }
     };
     STAMP(12);
@@ -1002,18 +1009,18 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
             // S2 = sum j^2 u_j over j <= k:
             //   sum p u_j = k S0 - S1,   sum p^2 u_j = k (k S0 - S1) - (k S1 - S2).
             // For this the jerk is re-dealt through LDS (the factor's storage is free by now)
-            // so that every lane holds NPL consecutive knots: the moments run serially inside
-            // a lane and need one prefix scan across the lanes each.
+            // so that every lane_e holds NPL consecutive knots: the moments run serially inside
+            // a lane_e and need one prefix scan across the lanes each.
             double *sx = W.Rinv, *sy = W.Rinv + 64 * NPL;
             static_assert(2 * 64 * NPL <= QL * LDI, "jerk exchange does not fit the factor storage");
             wsync();
 #pragma unroll
             for (int c = 0; c < NPL; c++) {
-                sx[lane + 64 * c] = jx[c];
-                if constexpr (POLY) sy[lane + 64 * c] = jy[c];
+                sx[lane_e + 64 * c] = jx[c];
+                if constexpr (POLY) sy[lane_e + 64 * c] = jy[c];
             }
             wsync();
-            const int k0 = NPL * lane;
+            const int k0 = NPL * lane_e;
             const double T1 = sd.Ts, T2 = T1 * T1, T3 = T2 * T1;
             auto integrate = [&](const double *su, const double *w, double *op, double *ov) {
                 if (!op && !ov) return;
@@ -1048,7 +1055,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 }
                 auto store_run = [&](double *o, const double *v) {
                     if (!o) return;
-                    double *dst = o + (size_t)inst * N + k0;
+                    double *dst = o + (size_t)inst_e * N + k0;
                     if ((NPL & 1) == 0 && (reinterpret_cast<size_t>(dst) & 15) == 0) {
 #pragma unroll
                         for (int i = 0; i + 1 < NPL; i += 2) {
@@ -1091,8 +1098,8 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
 #pragma unroll
         for (int c = 0; c < NPL; c++)
             if (KN(c) < N) {
-                if (out.zmp_x) out.zmp_x[(size_t)inst * N + KN(c)] = solved ? zx[c] : 0.0;
-                if (out.zmp_y) out.zmp_y[(size_t)inst * N + KN(c)] = solved ? zy[c] : 0.0;
+                if (out.zmp_x) out.zmp_x[(size_t)inst_e * N + KN(c)] = solved ? zx[c] : 0.0;
+                if (out.zmp_y) out.zmp_y[(size_t)inst_e * N + KN(c)] = solved ? zy[c] : 0.0;
                 if (out.min_margin) {
                     // getConstraintViolation (MPCPlanner.cpp:1132-1153)
                     double mn = DINF;
@@ -1100,7 +1107,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                     for (int e = 0; e < ES; e++)
                         if (validm & (1u << (4 * c + e)))
                             mn = fmin(mn, slotP(c, e) * zx[c] + slotQ(c, e) * zy[c] + slotR(c, e));
-                    out.min_margin[(size_t)inst * N + KN(c)] = solved ? mn : 0.0;
+                    out.min_margin[(size_t)inst_e * N + KN(c)] = solved ? mn : 0.0;
                 }
             }
     }
