@@ -373,44 +373,61 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
 
         __syncthreads();
         BSTAMP(0);
+        // Taking over from the first stage: its record holds the working set (in order) and the
+        // multipliers at the top of the outer iteration it could not finish.  The rows are put
+        // back one by one through the ordinary pass -- d, z, r and the update of J and T for an
+        // added constraint -- with the step length forced to zero and no decisions taken, then x
+        // follows from the multipliers (x = x_unc + G^-1 N u) and the method carries on with the
+        // record's objective and counters.
+        const int *wi = ws.warm_i ? ws.warm_i + (size_t)inst * WARM_STRIDE : nullptr;
+        const double *wd = ws.warm_d ? ws.warm_d + (size_t)inst * WARM_STRIDE : nullptr;
+        const int n_warm = wi ? ufirst(wi[WARM_N]) : 0;
+        int replay = n_warm; // rows still to be put back
+        if (n_warm > 0) R_norm = fmax(R_norm, wd[WARM_RNORM]);
         bool done = false;
         int ip = 0, kip = 0;
         double sgn = 1.0, ucand = 0.0, s_ip = 0.0;
         while (!done) { // step 1 (l1)
-            iters++;
-            if (iters > sd.iter_cap) {
-                status = MPCB_ITER_CAP;
-                break;
+            double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
+            if (replay == 0) {
+                iters++;
+                if (iters > sd.iter_cap) {
+                    status = MPCB_ITER_CAP;
+                    break;
+                }
+                eval_zmp();
+                BSTAMP(1);
+                falg += 2.0 * mm * nn;
+                row_vals(s00, s01, s10, s11);
+                exclm = 0xf;
+                // sum of infeasibilities (:255-261) and the most violated row among the rows that
+                // are neither active nor excluded (:279-287), lowest row on ties
+                double psi = 0.0;
+                if (v0) psi += fmin(0.0, s00) + fmin(0.0, s01);
+                if (v1) psi += fmin(0.0, s10) + fmin(0.0, s11);
+                psi = wave_sum(psi);
+                if (fabs(psi) <= sd.psi_thr) {
+                    zmp_current = true;
+                    break;
+                }
+                uo0 = u0;
+                uo1 = u1;
+                Ao0 = A0;
+                Ao1 = A1;
+                xo0 = x0r;
+                xo1 = x1r;
             }
-            eval_zmp();
-            BSTAMP(1);
-            falg += 2.0 * mm * nn;
-            double s00, s01, s10, s11;
-            row_vals(s00, s01, s10, s11);
-            exclm = 0xf;
-            // sum of infeasibilities (:255-261) and the most violated row among the rows that
-            // are neither active nor excluded (:279-287), lowest row on ties
-            double psi = 0.0;
-            if (v0) psi += fmin(0.0, s00) + fmin(0.0, s01);
-            if (v1) psi += fmin(0.0, s10) + fmin(0.0, s11);
-            psi = wave_sum(psi);
-            if (fabs(psi) <= sd.psi_thr) {
-                zmp_current = true;
-                break;
-            }
-            uo0 = u0;
-            uo1 = u1;
-            Ao0 = A0;
-            Ao1 = A1;
-            xo0 = x0r;
-            xo1 = x1r;
             double ssv = 0.0;
             bool restart;
             do { // step 2 (l2)
                 restart = false;
                 double bv = DINF;
                 int brow = 0x7fffffff, aux = 0;
-                {
+                if (replay > 0) {
+                    ip = ufirst(wi[n_warm - replay]);
+                    ssv = -1.0;
+                    s_ip = 0.0;
+                } else {
                     const unsigned ok = validm & ~actm & exclm;
                     auto consider = [&](double v, int row, unsigned bit) {
                         if ((ok & bit) && v < ssv && (v < bv || (v == bv && row < brow))) {
@@ -422,12 +439,12 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     consider(s10, i1, 4u);
                     consider(s01, N + i0, 2u);
                     consider(s11, N + i1, 8u);
-                }
-                wave_argmin(bv, brow, aux);
-                if (bv < ssv) {
-                    ssv = bv;
-                    ip = brow;
-                    s_ip = bv;
+                    wave_argmin(bv, brow, aux);
+                    if (bv < ssv) {
+                        ssv = bv;
+                        ip = brow;
+                        s_ip = bv;
+                    }
                 }
                 if (ssv >= 0.0) {
                     zmp_current = true; // x has not moved since the evaluation (or was restored)
@@ -436,18 +453,20 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                 }
                 kip = ip < N ? ip : ip - N;
                 sgn = ip < N ? 1.0 : -1.0;
-                ucand = 0.0;
+                ucand = replay > 0 ? wd[n_warm - replay] : 0.0; // (a row put back brings its multiplier)
                 BSTAMP(2);
                 double d0 = 0.0, d1 = 0.0;
                 bool d_valid = false; // d = J' n+ is current (a drop rotates it along with J)
                 for (;;) { // step 2a (l2a)
-                    passes++;
-                    if (passes > sd.iter_cap) {
-                        status = MPCB_ITER_CAP;
-                        done = true;
-                        break;
+                    if (replay == 0) {
+                        passes++;
+                        if (passes > sd.iter_cap) {
+                            status = MPCB_ITER_CAP;
+                            done = true;
+                            break;
+                        }
+                        falg += 2.0 * nn * nn + 2.0 * nn * (nn - iq) + (double)iq * iq;
                     }
-                    falg += 2.0 * nn * nn + 2.0 * nn * (nn - iq) + (double)iq * iq;
                     if (!d_valid) {
                         // ---- d = J' n+ : rows 0 .. kip in four bands, a lane's two columns ------
                         {
@@ -570,15 +589,17 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     }
                     wave_argmin(t1, kpos, aux2);
                     const double t2 = fabs(zz) > EPS ? -s_ip / zn : DINF; // :336-339
-                    const double t = fmin(t1, t2);
+                    const double t = replay > 0 ? 0.0 : fmin(t1, t2);
                     BSTAMP(7);
-                    if (t >= DINF) { // :350-356
+                    if (replay > 0) {
+                        // nothing moves: straight to the update for an added constraint
+                    } else if (t >= DINF) { // :350-356
                         status = MPCB_INFEASIBLE;
                         f = DINF;
                         done = true;
                         break;
                     }
-                    if (t2 >= DINF) { // dual step only, then drop (:358-373)
+                    if (replay == 0 && t2 >= DINF) { // dual step only, then drop (:358-373)
                         u0 -= t * r0v;
                         u1 -= t * r1v;
                         ucand += t;
@@ -587,16 +608,18 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                         continue;
                     }
                     // step in primal and dual space (:377-382)
-                    x0r = fma(t, z0, x0r);
-                    x1r = fma(t, z1, x1r);
-                    if (v0) xs[i0] = x0r;
-                    if (v1) xs[i1] = x1r;
-                    f += t * zn * (0.5 * t + ucand);
-                    u0 -= t * r0v;
-                    u1 -= t * r1v;
-                    ucand += t;
-                    if (t == t2) { // full step: add the constraint (:392-426, add_constraint :450-513)
-                        falg += 6.0 * nn * (nn - iq - 1);
+                    if (replay == 0) {
+                        x0r = fma(t, z0, x0r);
+                        x1r = fma(t, z1, x1r);
+                        if (v0) xs[i0] = x0r;
+                        if (v1) xs[i1] = x1r;
+                        f += t * zn * (0.5 * t + ucand);
+                        u0 -= t * r0v;
+                        u1 -= t * r1v;
+                        ucand += t;
+                    }
+                    if (t == t2 || replay > 0) { // full step: add the constraint (:392-426, add_constraint :450-513)
+                        if (replay == 0) falg += 6.0 * nn * (nn - iq - 1);
                         // suffix norms nu_j = ||d[j .. jt]|| and their reciprocals from one rsqrt chain:
                         // no division in the coefficients
                         double nu0 = 0.0, inu0 = 0.0, nu1 = 0.0, inu1 = 0.0;
@@ -675,7 +698,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                                 }
                             }
                         }
-                        if (rho <= EPS * R_norm) {
+                        if (replay == 0 && rho <= EPS * R_norm) {
                             // degenerate (:400-418): exclude ip, restore u, A and x of step 1,
                             // choose again
                             if (lane == (kip & 63)) exclm &= ~(1u << (2 * (kip >> 6) + (ip < N ? 0 : 1)));
@@ -720,6 +743,27 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                         }
                         if (lane == (kip & 63)) actm |= 1u << (2 * (kip >> 6) + (ip < N ? 0 : 1));
                         iq++;
+                        if (replay > 0) {
+                            __syncthreads(); // J and T as the next row's pass reads them
+                            if (--replay == 0) {
+                                // x = x_unc + G^-1 N u with G = weight_R I: row a contributes
+                                // +-u_a Zu[k_a, :] / weight_R (zc is zero left of the diagonal)
+                                for (int a = 0; a < n_warm; a++) {
+                                    const int l = __builtin_amdgcn_readlane(a >= HALF ? A1 : A0, a & 63);
+                                    const double ua = bcast(a >= HALF ? u1 : u0, a & 63);
+                                    const int ka = l < N ? l : l - N;
+                                    const double ca_ = (l < N ? ua : -ua) * inv_weight_R;
+                                    x0r = fma(ca_, zc[ka - i0], x0r);
+                                    x1r = fma(ca_, zc[ka - i1], x1r);
+                                }
+                                if (v0) xs[i0] = x0r;
+                                if (v1) xs[i1] = x1r;
+                                f = wd[WARM_F];
+                                falg = wd[WARM_FALG];
+                                iters = wi[WARM_ITERS];
+                                passes = wi[WARM_PASSES];
+                            }
+                        }
                         BSTAMP(9);
                         break; // goto l1 (its barrier publishes J and T)
                     }

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -320,11 +321,19 @@ int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
     if (B > h->list_capacity) {
         HIP_TRY(hipStreamSynchronize(stream));
         if (h->ws.list) HIP_TRY(hipFree(h->ws.list));
+        if (h->ws.warm_i) HIP_TRY(hipFree(h->ws.warm_i));
+        if (h->ws.warm_d) HIP_TRY(hipFree(h->ws.warm_d));
         h->ws.list = nullptr;
+        h->ws.warm_i = nullptr;
+        h->ws.warm_d = nullptr;
         h->list_capacity = 0;
         int cap = 1024;
         while (cap < B) cap *= 2;
         HIP_TRY(hipMalloc((void **)&h->ws.list, (size_t)cap * sizeof(int)));
+        if (mpcb::box_dense_applies(h->ds) && !std::getenv("MPCB_DEBUG_COLD_SECOND_STAGE")) { // hand-over records, one per instance of the batch
+            HIP_TRY(hipMalloc((void **)&h->ws.warm_i, (size_t)cap * mpcb::WARM_STRIDE * sizeof(int)));
+            HIP_TRY(hipMalloc((void **)&h->ws.warm_d, (size_t)cap * mpcb::WARM_STRIDE * sizeof(double)));
+        }
         h->list_capacity = cap;
     }
     if (h->dense_in_lds) return 0;
@@ -405,7 +414,13 @@ int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &o
     }
     // the slack formulation keeps about 2N rows active: beyond the first stage's capacity
     if (h->params.solver_mode == MPCB_MODE_DENSE || h->params.formulation == MPCB_BOX_SLACK) {
-        HIP_TRY(mpcb::launch_list_all(ws, B, stream));
+        // no first stage: nothing to take over, the records (if any) are stale
+        mpcb::DenseWs cold = ws;
+        cold.warm_i = nullptr;
+        cold.warm_d = nullptr;
+        HIP_TRY(mpcb::launch_list_all(cold, B, stream));
+        HIP_TRY(mpcb::launch_dense(h->ds, di, out, cold, dense_grid, stream));
+        return 0;
     } else {
         HIP_TRY(hipMemsetAsync(ws.count, 0, sizeof(int), stream));
         HIP_TRY(mpcb::launch_zspace(h->ds, di, out, B, ws, stream));
@@ -438,6 +453,8 @@ void mpcb_destroy(mpcb_handle h) {
         }
         for (void *p : h->dev_allocs) (void)hipFree(p);
         if (h->ws.list) (void)hipFree(h->ws.list);
+        if (h->ws.warm_i) (void)hipFree(h->ws.warm_i);
+        if (h->ws.warm_d) (void)hipFree(h->ws.warm_d);
         if (h->ws.J) (void)hipFree(h->ws.J);
         if (h->ws.R) (void)hipFree(h->ws.R);
         if (h->stage_dev) (void)hipFree(h->stage_dev);

@@ -51,9 +51,23 @@ struct DevIn {
 
 // Hand-over from the wave-per-QP kernel to the dense kernel, and the dense kernel's
 // tables and HBM workspace.
+// Record the first stage leaves for an instance it hands over (box problems with the
+// LDS-resident second stage only, else the pointers are NULL): the state at the top of the
+// outer iteration it could not finish -- working set in order, multipliers, objective and the
+// counters -- so that the second stage rebuilds its factors for that working set and carries
+// on from there instead of repeating those iterations.
+constexpr int WARM_QL = 32;       // rows a record can hold (>= the first stage's capacity)
+constexpr int WARM_STRIDE = 36;   // per instance: [0, WARM_QL) rows resp. multipliers, then
+constexpr int WARM_N = 32;        //   warm_i: number of rows, outer iterations, passes
+constexpr int WARM_ITERS = 33;    //   warm_d: objective, operation count, R_norm
+constexpr int WARM_PASSES = 34;
+constexpr int WARM_F = 32, WARM_FALG = 33, WARM_RNORM = 34;
+
 struct DenseWs {
     int *list;                 // instance indices the first stage could not certify
     int *count;                // how many
+    int *warm_i;               // [B][WARM_STRIDE] hand-over records (see above), or NULL
+    double *warm_d;            // [B][WARM_STRIDE]
     double *J, *R;             // workspace: one n x n slot of each per resident workgroup
     const double *J1;          // L1^-T (N x N, column-major, upper triangular)
     const double *zu_col, *xp_col, *xv_col; // Toeplitz first columns of Zu, Xpu, Xvu

@@ -49,8 +49,11 @@ struct WaveState {
     double cx[QL + 4], cy[QL + 4];                      // row coefficients, zero-padded to a multiple of 4
     int wsRow[QL + 1], wsKS[QL + 4];                    // constraint row; (knot << 2) | slot
     int oldRow[QL + 1], oldKS[QL + 1];
-    int pad[3];
+    // scalars as of the top of the current outer iteration (for the hand-over record)
+    int topPasses, topIq, pad;
+    double topF, topFalg;
 };
+static_assert(QL <= WARM_QL, "a hand-over record holds the whole working set");
 static_assert(QL <= 64 && QL % 4 == 0, "one lane per working-set position; products run four terms per trip");
 static_assert(sizeof(WaveState) % 8 == 0, "tab must stay 8-byte aligned");
 
@@ -175,7 +178,8 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
 // Kz = Kzp - c Kza with c = height / gravity (three loads per entry instead of one).
 template <int NPL, bool POLY, bool ROWS, bool HV>
 __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
-                                                      int *unresolved_list, int *unresolved_count) {
+                                                      int *unresolved_list, int *unresolved_count,
+                                                      int *warm_i, double *warm_d) {
     constexpr int ES = POLY ? 4 : 2;
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63;
@@ -609,6 +613,12 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
             W.oldRow[lane] = W.wsRow[lane];
             W.oldKS[lane] = W.wsKS[lane];
         }
+        if (warm_i && lane == 0) {
+            W.topPasses = passes;
+            W.topIq = iq;
+            W.topF = f;
+            W.topFalg = (double)(falg - 2 * mm * nn); // (this iteration's row evaluation is counted again by whoever redoes it)
+        }
         STAMP(2);
         double ssv = 0.0;
         bool done = false, restart, restart_seen = false;
@@ -949,6 +959,24 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     const bool solved = status == MPCB_OK || status == MPCB_ITER_CAP;
     if (status == STATUS_UNRESOLVED && lane_e == 0 && unresolved_list)
         unresolved_list[atomicAdd(unresolved_count, 1)] = inst_e; // re-solved by the dense kernel
+    if (status == STATUS_UNRESOLVED && warm_i) {
+        // where the dense kernel takes over: the top of this outer iteration
+        int *wi = warm_i + (size_t)inst_e * WARM_STRIDE;
+        double *wd = warm_d + (size_t)inst_e * WARM_STRIDE;
+        const int ntop = ufirst(W.topIq);
+        if (lane_e < ntop) {
+            wi[lane_e] = W.oldRow[lane_e];
+            wd[lane_e] = W.oldU[lane_e];
+        }
+        if (lane_e == 0) {
+            wi[WARM_N] = ntop;
+            wi[WARM_ITERS] = iters - 1;
+            wi[WARM_PASSES] = W.topPasses;
+            wd[WARM_F] = W.topF;
+            wd[WARM_FALG] = W.topFalg;
+            wd[WARM_RNORM] = R_norm;
+        }
+    }
     if (lane_e == 0) {
         if (out.cost) out.cost[inst_e] = f;
         if (out.status) out.status[inst_e] = status;
@@ -1135,7 +1163,8 @@ hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &o
         if (e != hipSuccess) return e;
     }
     const int blocks = (B + wpb - 1) / wpb;
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64 * wpb), shmem, stream, sd, in, out, B, ws.list, ws.count);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64 * wpb), shmem, stream, sd, in, out, B, ws.list, ws.count, ws.warm_i,
+                       ws.warm_d);
     return hipGetLastError();
 }
 

