@@ -31,10 +31,13 @@ namespace mpcb {
 namespace {
 
 constexpr int QL = 32;                   // capacity of the LDS-resident factor
-// Box problems hand over earlier: their dense second stage is LDS-resident and fast, and the
-// instances that fill the factor there are the numerically infeasible ones, which run to ~100
-// active rows whatever the capacity -- every iteration they spend here is repeated there.
-constexpr int QL_BOX = 24;
+// Box problems hand over a little earlier.  What fills the factor there are the numerically
+// infeasible draws, which run to ~100 active rows whatever the capacity; the dense second
+// stage (LDS-resident, built for the latency of one hard instance) takes over where this kernel
+// stopped, so nothing is repeated, but this kernel's passes get slower as the working set grows
+// while the second stage, one instance per compute unit, is paid once per round of 256
+// instances.  Measured on the 4,096-pair batch: 20 -> 2.87, 24 -> 2.78, 28 -> 2.63, 30 -> 3.04 ms.
+constexpr int QL_BOX = 28;
 constexpr int TRI = QL * (QL + 1) / 2;   // packed upper triangle, column-major
 constexpr int LDI = QL + 1;
 
