@@ -68,11 +68,17 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
                             __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 
-// Remove working-set position qq (delete_constraint, eiquadprog.hpp:516-592).
+// Remove working-set position qq (delete_constraint, eiquadprog.hpp:516-592), the reference's way:
 // R loses column qq and is re-triangularised by Givens rotations of rows (j, j+1);
 // the same rotations applied to the columns of R^-1, minus row qq and the last
 // column, give the new inverse -- what the reference does to the columns of J.
-__device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq, int qq) {
+// (Kept for the box problems.  Its rotation angles come from R, whose update is backward stable,
+// so T picks up only rounding-level errors per drop; the closed form below takes the angles from
+// T itself, whose errors then compound when the working set is nearly dependent.  Every regular
+// instance is solved identically by both, but the numerically infeasible box draws lose the
+// reduced system's accuracy after a handful of rows with the closed form and are handed to the
+// second stage almost from scratch -- 3.9 instead of 2.6 ms per decoupled step.)
+__device__ __forceinline__ void drop_constraint_rotations(WaveState &W, int lane, int &iq, int qq) {
     // working-set arrays: positions qq+1 .. iq-1 move down by one
     double tu = 0, tp = 0, tq = 0;
     int trow = 0, tks = 0;
@@ -155,6 +161,72 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
     }
     wsync();
     if (ri) W.Rinv[lane * LDI + iq - 1] = 0.0; // the vacated last column
+    iq--;
+    wsync();
+}
+
+// Remove working-set position qq (delete_constraint, eiquadprog.hpp:516-592).
+// The reference deletes column qq of R and restores the triangle with plane rotations of the rows
+// (j, j+1), j = qq .. iq-2, applying the same rotations to the columns of J.  Here only T = R^-1
+// is kept, and those rotations are the ones that move row qq of T -- entries g_j = T(qq, j),
+// j = qq .. iq-1 -- into its last entry.  With the prefix norms rho_j = ||g[qq .. j]|| and the
+// prefix sums Q_j = sum_{c = qq .. j} g_c col_c of the old columns, the whole sequence has the
+// closed form
+//     new col_j = g_{j+1} / (rho_{j+1} rho_j) Q_j - (rho_j / rho_{j+1}) col_{j+1},   qq <= j < iq-1
+// (up to the signs of columns, which cancel in every product the method forms); row qq and the
+// last column drop out.  All rotation coefficients come from one prefix scan and one reciprocal
+// square root per lane; what remains sequential is a chain of two fused multiply-adds per
+// column in every row.
+__device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq, int qq) {
+    // working-set arrays: positions qq+1 .. iq-1 move down by one
+    double tu = 0, tp = 0, tq = 0;
+    int trow = 0, tks = 0;
+    const bool mv = lane > qq && lane < iq;
+    if (mv) {
+        tu = W.wsU[lane];
+        tp = W.wsP[lane];
+        tq = W.wsQ[lane];
+        trow = W.wsRow[lane];
+        tks = W.wsKS[lane];
+    }
+    wsync();
+    if (mv) {
+        W.wsU[lane - 1] = tu;
+        W.wsP[lane - 1] = tp;
+        W.wsQ[lane - 1] = tq;
+        W.wsRow[lane - 1] = trow;
+        W.wsKS[lane - 1] = tks;
+    }
+    const int last = iq - 1; // columns qq .. last take part, column last goes
+    const bool ri = lane < iq;
+    const int li = lane < QL ? lane : QL - 1;
+    if (qq < last) {
+        // lane j: g_j, rho_j and the coefficients of column j
+        const bool gj = lane >= qq && lane <= last;
+        const double g = gj ? W.Rinv[qq * LDI + li] : 0.0;
+        const double p = wave_scan(g * g);
+        double rho = 0.0, irho = 0.0;
+        sqrt_rsqrt(p > 0.0 ? p : 1.0, rho, irho);
+        rho = p > 0.0 ? rho : 0.0;
+        irho = p > 0.0 ? irho : 0.0;
+        const double gn = dpp_f64<0x130, 0xF>(0.0, g), irn = dpp_f64<0x130, 0xF>(0.0, irho); // of lane + 1
+        const bool cj = lane >= qq && lane < last;
+        const double a = cj ? gn * (irn * irho) : 0.0, b = cj ? -rho * irn : 0.0;
+        // lane i: row i of T; rows below qq move up by one
+        const int inew = lane < qq ? lane : lane - 1;
+        const bool wr = ri && lane != qq;
+        double cur = ri ? W.Rinv[li * LDI + qq] : 0.0, q = 0.0;
+        for (int j = qq; j < last; j++) {
+            const double nxt = ri ? W.Rinv[li * LDI + j + 1] : 0.0;
+            q = fma(lane_bcast(g, j), cur, q);
+            const double o = fma(lane_bcast(a, j), q, lane_bcast(b, j) * nxt);
+            if (wr) W.Rinv[inew * LDI + j] = o;
+            cur = nxt;
+            wsync(); // column j + 1 of every row is read before anything is stored over it
+        }
+    }
+    wsync();
+    if (ri) W.Rinv[lane * LDI + last] = 0.0; // the vacated last column
     iq--;
     wsync();
 }
@@ -854,7 +926,8 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                         const long long cdrop = iq - 1 - apos;
                         falg += 6 * nn * cdrop + 3 * cdrop * (cdrop - 1);
                     }
-                    drop_constraint(W, lane, iq, apos);
+                    if constexpr (POLY) drop_constraint(W, lane, iq, apos);
+                    else drop_constraint_rotations(W, lane, iq, apos);
                     {
                         const double up = dpp_f64<0x130, 0xF>(0.0, ga); // wave_shl:1 -- value of lane + 1
                         ga = lane >= apos ? up : ga;
@@ -910,13 +983,14 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                         break;
                     }
                     R_norm = fmax(R_norm, rho);
-                    const int off = tri(iq);
                     STAMP(10);
+                    if constexpr (!POLY) { // R is kept for drop_constraint_rotations
+                        if (lane < iq) W.R[tri(iq) + lane] = da;
+                        else if (lane == iq) W.R[tri(iq) + iq] = rho;
+                    }
                     if (lane < iq) {
-                        W.R[off + lane] = da;
                         W.Rinv[lane * LDI + iq] = -ra * irho;
                     } else if (lane == iq) {
-                        W.R[off + iq] = rho;
                         W.Rinv[iq * LDI + iq] = irho;
                         W.wsU[iq] = ucand;
                         W.wsP[iq] = pip;
@@ -941,7 +1015,8 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                     const long long cdrop = iq - 1 - apos;
                     falg += 6 * nn * cdrop + 3 * cdrop * (cdrop - 1);
                 }
-                drop_constraint(W, lane, iq, apos);
+                if constexpr (POLY) drop_constraint(W, lane, iq, apos);
+                else drop_constraint_rotations(W, lane, iq, apos);
                 {
                     const double up = dpp_f64<0x130, 0xF>(0.0, ga); // wave_shl:1 -- value of lane + 1
                     ga = lane >= apos ? up : ga;
