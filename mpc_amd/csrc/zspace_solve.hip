@@ -30,19 +30,23 @@
 namespace mpcb {
 namespace {
 
-constexpr int QL = 32;                   // capacity of the LDS-resident factor
-// Box problems hand over a little earlier.  What fills the factor there are the numerically
-// infeasible draws, which run to ~100 active rows whatever the capacity; the dense second
-// stage (LDS-resident, built for the latency of one hard instance) takes over where this kernel
-// stopped, so nothing is repeated, but this kernel's passes get slower as the working set grows
-// while the second stage, one instance per compute unit, is paid once per round of 256
-// instances.  Measured on the 4,096-pair batch: 20 -> 2.87, 24 -> 2.78, 28 -> 2.63, 30 -> 3.04 ms.
+// Capacity of the LDS-resident factor.  The coupled forms at the common horizons (up to 256
+// knots) get by with 28 rows and no R (see drop_constraint): 13 KB of LDS per wave, which lets
+// twelve single-wave workgroups share a compute unit -- three per SIMD -- where the register
+// budget allows it.  The box form keeps R (drop_constraint_rotations) and 32 rows of storage.
+// Box problems hand over a little earlier than their storage would force them to.  What fills the
+// factor there are the numerically infeasible draws, which run to ~100 active rows whatever the
+// capacity; the dense second stage (LDS-resident, built for the latency of one hard instance)
+// takes over where this kernel stopped, so nothing is repeated, but this kernel's passes get
+// slower as the working set grows while the second stage, one instance per compute unit, is paid
+// once per round of 256 instances.  Measured on the 4,096-pair batch: 20 -> 2.87, 24 -> 2.78,
+// 28 -> 2.63, 30 -> 3.04 ms.
 constexpr int QL_BOX = 28;
-constexpr int TRI = QL * (QL + 1) / 2;   // packed upper triangle, column-major
-constexpr int LDI = QL + 1;
 
-struct WaveState {
-    double R[TRI];
+template <int QL_, bool KEEP_R>
+struct WaveStateT {
+    static constexpr int QL = QL_, LDI = QL_ + 1, TRI = QL_ * (QL_ + 1) / 2;
+    double R[KEEP_R ? TRI : 1]; // packed upper triangle, column-major
     // R^-1 as a full square with leading dimension LDI (odd: a column read by rows is
     // conflict-free).  Everything outside the leading iq x iq upper triangle is kept zero, so
     // the products with it need no masks.
@@ -50,15 +54,20 @@ struct WaveState {
     double wsU[QL + 1], wsP[QL + 1], wsQ[QL + 1];       // working set: multiplier, p, q
     double oldU[QL + 1];                                // copy taken at step 1 (eiquadprog.hpp:275-277)
     double cx[QL + 4], cy[QL + 4];                      // row coefficients, zero-padded to a multiple of 4
+    double topF, topFalg;                               // scalars as of the top of the current outer
+    int topPasses, topIq;                               //   iteration (for the hand-over record)
     int wsRow[QL + 1], wsKS[QL + 4];                    // constraint row; (knot << 2) | slot
     int oldRow[QL + 1], oldKS[QL + 1];
-    // scalars as of the top of the current outer iteration (for the hand-over record)
-    int topPasses, topIq, pad;
-    double topF, topFalg;
+    int pad; // (4 QL + 9 ints above: an odd number)
 };
-static_assert(QL <= WARM_QL, "a hand-over record holds the whole working set");
-static_assert(QL <= 64 && QL % 4 == 0, "one lane per working-set position; products run four terms per trip");
-static_assert(sizeof(WaveState) % 8 == 0, "tab must stay 8-byte aligned");
+template <bool POLY, int NPL>
+struct WaveConfig {
+    static constexpr int QL = (POLY && NPL <= 4) ? 28 : 32;
+    typedef WaveStateT<QL, !POLY> State;
+    static_assert(QL <= WARM_QL, "a hand-over record holds the whole working set");
+    static_assert(QL <= 64 && QL % 4 == 0, "one lane per working-set position; products run four terms per trip");
+    static_assert(sizeof(State) % 8 == 0, "tab must stay 8-byte aligned");
+};
 
 __device__ __forceinline__ int tri(int col) { return col * (col + 1) / 2; }
 
@@ -78,7 +87,9 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 // instance is solved identically by both, but the numerically infeasible box draws lose the
 // reduced system's accuracy after a handful of rows with the closed form and are handed to the
 // second stage almost from scratch -- 3.9 instead of 2.6 ms per decoupled step.)
+template <class WaveState>
 __device__ __forceinline__ void drop_constraint_rotations(WaveState &W, int lane, int &iq, int qq) {
+    constexpr int QL = WaveState::QL, LDI = WaveState::LDI;
     // working-set arrays: positions qq+1 .. iq-1 move down by one
     double tu = 0, tp = 0, tq = 0;
     int trow = 0, tks = 0;
@@ -177,7 +188,9 @@ __device__ __forceinline__ void drop_constraint_rotations(WaveState &W, int lane
 // last column drop out.  All rotation coefficients come from one prefix scan and one reciprocal
 // square root per lane; what remains sequential is a chain of two fused multiply-adds per
 // column in every row.
+template <class WaveState>
 __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq, int qq) {
+    constexpr int QL = WaveState::QL, LDI = WaveState::LDI;
     // working-set arrays: positions qq+1 .. iq-1 move down by one
     double tu = 0, tp = 0, tq = 0;
     int trow = 0, tks = 0;
@@ -256,6 +269,8 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                                                       int *unresolved_list, int *unresolved_count,
                                                       int *warm_i, double *warm_d) {
     constexpr int ES = POLY ? 4 : 2;
+    typedef typename WaveConfig<POLY, NPL>::State WaveState;
+    constexpr int QL = WaveState::QL, LDI = WaveState::LDI;
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63;
     const int wv = ufirst((int)(threadIdx.x >> 6));
@@ -1227,7 +1242,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
 template <int NPL, bool POLY, bool ROWS, bool HV>
 hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
                       const DenseWs &ws, hipStream_t stream) {
-    const size_t per_wave = sizeof(WaveState) +
+    const size_t per_wave = sizeof(typename WaveConfig<POLY, NPL>::State) +
                             (POLY ? ((size_t)(sd.nphase + 1) * 12 + 2 * (size_t)std::max(sd.nphase, sd.nref)) * 8 : 0);
     // One wave (= one QP) per workgroup: waves never wait for each other, so a workgroup's LDS
     // and wave slot are released the moment its QP is done instead of when the slowest of
