@@ -30,10 +30,11 @@
 namespace mpcb {
 namespace {
 
-// Capacity of the LDS-resident factor.  The coupled forms at the common horizons (up to 256
-// knots) get by with 28 rows and no R (see drop_constraint): 13 KB of LDS per wave, which lets
-// twelve single-wave workgroups share a compute unit -- three per SIMD -- where the register
-// budget allows it.  The box form keeps R (drop_constraint_rotations) and 32 rows of storage.
+// Capacity of the LDS-resident factor: 32 rows.  The coupled forms keep no R (see
+// drop_constraint), the box form does (drop_constraint_rotations).  (Three waves per SIMD for the
+// coupled forms -- 28 rows, 13 KB of LDS per wave, 168 registers -- were tried: the compiler does
+// not get this kernel below ~95 spilled registers at that budget, and with spills it runs at two
+// thirds of the speed of the two-wave build.)
 // Box problems hand over a little earlier than their storage would force them to.  What fills the
 // factor there are the numerically infeasible draws, which run to ~100 active rows whatever the
 // capacity; the dense second stage (LDS-resident, built for the latency of one hard instance)
@@ -62,7 +63,7 @@ struct WaveStateT {
 };
 template <bool POLY, int NPL>
 struct WaveConfig {
-    static constexpr int QL = (POLY && NPL <= 4) ? 28 : 32;
+    static constexpr int QL = 32;
     typedef WaveStateT<QL, !POLY> State;
     static_assert(QL <= WARM_QL, "a hand-over record holds the whole working set");
     static_assert(QL <= 64 && QL % 4 == 0, "one lane per working-set position; products run four terms per trip");
