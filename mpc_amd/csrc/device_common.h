@@ -131,9 +131,28 @@ __device__ __forceinline__ int wave_argmin(double &val, int &key, int &aux) {
     const unsigned long long win = __ballot(cand && key == k);
     const int src = win ? __ffsll((long long)win) - 1 : 0;
     aux = __builtin_amdgcn_readlane(aux, src);
-    val = m;
     key = k;
+    val = m;
     return src;
+}
+
+// The same reductions over the first 16 lanes only (one DPP row: four butterfly steps, no
+// cross-row steps); the other lanes' values are ignored.  Results are wave-uniform.
+__device__ __forceinline__ double row0_sum(double v) {
+    v += dpp_perm_f64<0xB1>(v);
+    v += dpp_perm_f64<0x4E>(v);
+    v += dpp_perm_f64<0x141>(v);
+    v += dpp_perm_f64<0x140>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0),
+                            __builtin_amdgcn_readlane(__double2loint(v), 0));
+}
+__device__ __forceinline__ double row0_min(double v) {
+    v = fmin(v, dpp_perm_f64<0xB1>(v));
+    v = fmin(v, dpp_perm_f64<0x4E>(v));
+    v = fmin(v, dpp_perm_f64<0x141>(v));
+    v = fmin(v, dpp_perm_f64<0x140>(v));
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0),
+                            __builtin_amdgcn_readlane(__double2loint(v), 0));
 }
 
 // s = sqrt(x) and is = 1/sqrt(x) for x > 0 from ONE dependent chain (hardware reciprocal

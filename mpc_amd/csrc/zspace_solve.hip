@@ -880,7 +880,14 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                     ra = lane < iq ? ra : 0.0;
                 }
                 STAMP(5);
-                const double zn = ufirst(mii - wave_sum(da * da)); // z . n_ip
+                // (d, r and the step lengths live on the first iq lanes: while the working set fits
+                // one row of 16 lanes the reductions over them skip the cross-row steps)
+                // (The box form keeps the full-wave sum: the paths of its numerically infeasible draws
+                // -- ~200 outer iterations each, and with them the running time of the second stage --
+                // change with the last bit of zn, and a different contraction of da * da into the
+                // first addition is enough for that.)
+                const bool small_ws = iq <= 16;
+                const double zn = ufirst(mii - ((POLY && small_ws) ? row0_sum(da * da) : wave_sum(da * da))); // z . n_ip
                 // rho = sqrt(zn) is the new diagonal entry of R if the constraint is added; its
                 // reciprocal also gives the full step length t2 = -s_ip / zn without a division
                 // (computed without a branch so that this chain and the division chain of the
@@ -891,8 +898,15 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 irho = zn > 0.0 ? ufirst(irho) : 0.0;
                 // step 2b: t1 = min u_k / r_k over r_k > 0, first minimum wins (:322-334)
                 double t1 = (lane < iq && ra > 0.0) ? ua / ra : DINF;
-                int apos = lane, dummy = 0;
-                wave_argmin(t1, apos, dummy);
+                int apos = lane;
+                {
+                    const double tmin = small_ws ? row0_min(t1) : wave_min(t1);
+                    // lowest position among the lanes that attain the minimum (all hold +inf if
+                    // no r is positive: position 0 then, which nothing uses)
+                    const unsigned long long win = __ballot(t1 == tmin);
+                    apos = win ? __ffsll((long long)win) - 1 : 0;
+                    t1 = tmin;
+                }
                 STAMP(6);
                 // z != 0 test (:336): ||z||^2 >= zn / lambda_max(G1) >= zn / trace(G1)
                 bool znz;
