@@ -1,0 +1,30 @@
+"""Full-size coupled batch (8,192 instances, velocity form) on the GPU against the CPU restatement:
+status, iteration counts and ordered working sets of every instance, trajectories to 1e-6."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from mpc_amd import batches, planner as P  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+form = sys.argv[2] if len(sys.argv) > 2 else "COUPLED_VEL"
+N, steps = 200, 20
+bt = batches.coupled_batch(B)
+t = time.time()
+ref = O.coupled_batch(O.params(N, R=0.01, Q=1.0, height=0.5), getattr(O, form), steps, 1000, bt["x0"], bt["y0"],
+                      bt["speed"], bt["feet_x"], bt["feet_y"], bt["swing0"], nthreads=16)
+print("cpu restatement: %.1f s" % (time.time() - t))
+pl = P.BatchedPlanner(N, formulation=getattr(P, form), weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
+o = {k: v.cpu().numpy() for k, v in pl.solve_coupled(**bt).items()}
+bad_ws = [i for i in range(B)
+          if list(o["active_idx"][i, :o["n_active"][i]]) != list(ref["active"][i, :ref["n_active"][i]])]
+worst = max(np.abs(o[k] - ref[k]).max() / np.abs(ref[k]).max() for k in ("jerk_x", "jerk_y", "com_x", "com_y", "zmp_x", "zmp_y"))
+print("%s, %d instances: status differs on %d, iteration count on %d, ordered working set on %d; worst relative "
+      "trajectory error %.2e; handed over %d" %
+      (form, B, int((o["status"] != ref["status"]).sum()), int((o["iters"] != ref["iters"]).sum()), len(bad_ws), worst,
+       pl.last_handover_count()))
