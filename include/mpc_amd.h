@@ -172,7 +172,7 @@ int  mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in,
  * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No
  * counterpart in the reference.  mpcb_solve_coupled_device sizes its hand-over list and the
  * dense second stage's J / R slots with hipMalloc on first use and when a batch outgrows them;
- * this entry point keeps them in a static device array instead (19.8 MiB per GPU, held from
+ * this entry point keeps them in a static device array instead (20.0 MiB per GPU, held from
  * the moment the library is loaded on that GPU until the process ends) and calls no hipMalloc,
  * hipFree or other allocating routine.  Limits, rejected with MPCB_E_ARG: B <= 65536 and at
  * most 400 variables per QP (horizon <= 200); the dense stage has 8 slots, so a batch that
@@ -243,6 +243,12 @@ int  mpcb_solve_unconstrained(mpcb_handle h, int32_t B, const double *x0, const 
  * solve the first-stage kernel handed over to the dense second-stage kernel (working set
  * beyond its capacity, or a numerically singular reduced system).  Waits for the device. */
 int  mpcb_last_handover_count(mpcb_handle h);
+
+/* Diagnostic, no counterpart in the reference: how many instances of the handle's most recent
+ * coupled solve outgrew the 32 working-set rows of the first-stage kernel and were solved by its
+ * wide edition (60 rows, a quarter of the occupancy) instead; those beyond 60 rows are part of
+ * mpcb_last_handover_count.  Always 0 for box problems.  Waits for the device. */
+int  mpcb_last_wide_count(mpcb_handle h);
 
 /* Diagnostic builds only (library compiled with -DMPCB_STAMPS): device buffer of 16 cycle
  * counters per instance that the kernels fill; a no-op pointer store in the normal build. */

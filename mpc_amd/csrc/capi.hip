@@ -48,10 +48,11 @@ constexpr int NOALLOC_MAX_BATCH = 65536;   // instances per call
 constexpr int NOALLOC_MAX_NVAR = 400;      // variables of one QP (horizon 200, both axes)
 constexpr int NOALLOC_SLOTS = 8;           // J / R slots of the dense stage
 constexpr size_t SCRATCH_LIST_OFF = 256;
-constexpr size_t SCRATCH_J_OFF = SCRATCH_LIST_OFF + (size_t)NOALLOC_MAX_BATCH * sizeof(int);
+constexpr size_t SCRATCH_WIDE_OFF = SCRATCH_LIST_OFF + (size_t)NOALLOC_MAX_BATCH * sizeof(int);
+constexpr size_t SCRATCH_J_OFF = SCRATCH_WIDE_OFF + (size_t)NOALLOC_MAX_BATCH * sizeof(int);
 constexpr size_t SCRATCH_SLOT_BYTES = (size_t)NOALLOC_MAX_NVAR * NOALLOC_MAX_NVAR * sizeof(double);
 constexpr size_t SCRATCH_R_OFF = SCRATCH_J_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BYTES;
-constexpr size_t SCRATCH_BYTES = SCRATCH_R_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BYTES; // 19.8 MiB
+constexpr size_t SCRATCH_BYTES = SCRATCH_R_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BYTES; // 20.0 MiB
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 constexpr int MAX_DEVICES = 64;
 static unsigned char *g_scratch[MAX_DEVICES] = {nullptr};
@@ -66,6 +67,7 @@ struct mpcb_handle_s {
     int dense_slots = 0;     // slots of ws.J / ws.R (HBM-resident dense factors only)
     int slot_target = 16;    // slots wanted: raised to the largest hand-over count seen (<= 512)
     bool dense_in_lds = false; // the dense kernel keeps J and R in LDS: no HBM slots at all
+    bool wide_fits = false;    // the wide edition of the first-stage kernel fits the LDS for this shape
     std::vector<void *> dev_allocs;   // tables: freed by mpcb_destroy only
     // hand-over count of the latest solve, copied to page-locked host memory behind the kernels;
     // read (without waiting) at the start of the next solve to size the dense workspace
@@ -275,17 +277,20 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
     }
     {
         int *cnt = nullptr;
-        if (hipMalloc((void **)&cnt, sizeof(int)) != hipSuccess) {
+        if (hipMalloc((void **)&cnt, 2 * sizeof(int)) != hipSuccess) { // hand-overs to the dense kernel, to the wide edition
             mpcb_destroy(h);
             return fail(MPCB_E_HIP, "hipMalloc failed");
         }
         h->dev_allocs.push_back(cnt);
         h->ws.count = cnt;
+        h->ws.wide_count = cnt + 1;
     }
     if (params->formulation != MPCB_UNCONSTRAINED) {
         // the dense kernel's LDS carve-up must fit a workgroup: found out here, not at the
         // first solve
         const size_t lds = mpcb::dense_lds_bytes_needed(ds, &h->dense_in_lds);
+        h->wide_fits = params->formulation != MPCB_BOX_1D && params->formulation != MPCB_BOX_SLACK &&
+                       mpcb::zspace_wide_lds_bytes(ds) <= 160 * 1024 - 256;
         if (lds > 160 * 1024) {
             mpcb_destroy(h);
             return fail(MPCB_E_ARG, "horizon / number_of_steps too large for this formulation: the dense "
@@ -321,15 +326,19 @@ int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
     if (B > h->list_capacity) {
         HIP_TRY(hipStreamSynchronize(stream));
         if (h->ws.list) HIP_TRY(hipFree(h->ws.list));
+        if (h->ws.wide_list) HIP_TRY(hipFree(h->ws.wide_list));
         if (h->ws.warm_i) HIP_TRY(hipFree(h->ws.warm_i));
         if (h->ws.warm_d) HIP_TRY(hipFree(h->ws.warm_d));
         h->ws.list = nullptr;
+        h->ws.wide_list = nullptr;
         h->ws.warm_i = nullptr;
         h->ws.warm_d = nullptr;
         h->list_capacity = 0;
         int cap = 1024;
         while (cap < B) cap *= 2;
         HIP_TRY(hipMalloc((void **)&h->ws.list, (size_t)cap * sizeof(int)));
+        if (h->params.formulation != MPCB_BOX_1D && h->params.formulation != MPCB_BOX_SLACK && h->wide_fits)
+            HIP_TRY(hipMalloc((void **)&h->ws.wide_list, (size_t)cap * sizeof(int)));
         if (mpcb::box_dense_applies(h->ds) && !std::getenv("MPCB_DEBUG_COLD_SECOND_STAGE")) { // hand-over records, one per instance of the batch
             HIP_TRY(hipMalloc((void **)&h->ws.warm_i, (size_t)cap * mpcb::WARM_STRIDE * sizeof(int)));
             HIP_TRY(hipMalloc((void **)&h->ws.warm_d, (size_t)cap * mpcb::WARM_STRIDE * sizeof(double)));
@@ -395,7 +404,11 @@ int ensure_knot_reference_tables(mpcb_handle h) {
     return 0;
 }
 
-// first stage (wave per QP), then the dense kernel over whatever it handed over
+// workgroups of the wide edition of the first-stage kernel (four fit a compute unit)
+constexpr int WIDE_GRID = 1024;
+
+// first stage (wave per QP; for the coupled forms its wide edition over the instances whose
+// working set outgrew the first), then the dense kernel over whatever is left
 int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &out, int B,
                      const mpcb::DenseWs &ws, int dense_grid, hipStream_t stream) {
     if (di.zref_knot_mode) {
@@ -406,9 +419,13 @@ int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &o
         ds.F2 = h->knot_F2;
         ds.F3 = h->knot_F3;
         ds.nref = ds.N;
-        HIP_TRY(hipMemsetAsync(ws.count, 0, sizeof(int), stream));
-        if (h->params.solver_mode == MPCB_MODE_DENSE) HIP_TRY(mpcb::launch_list_all(ws, B, stream));
-        else HIP_TRY(mpcb::launch_zspace(ds, di, out, B, ws, stream));
+        HIP_TRY(hipMemsetAsync(ws.count, 0, 2 * sizeof(int), stream));
+        if (h->params.solver_mode == MPCB_MODE_DENSE) {
+            HIP_TRY(mpcb::launch_list_all(ws, B, stream));
+        } else {
+            HIP_TRY(mpcb::launch_zspace(ds, di, out, B, ws, stream));
+            HIP_TRY(mpcb::launch_zspace_wide(ds, di, out, B < WIDE_GRID ? B : WIDE_GRID, ws, stream));
+        }
         HIP_TRY(mpcb::launch_dense(ds, di, out, ws, dense_grid, stream));
         return 0;
     }
@@ -418,12 +435,14 @@ int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &o
         mpcb::DenseWs cold = ws;
         cold.warm_i = nullptr;
         cold.warm_d = nullptr;
+        HIP_TRY(hipMemsetAsync(ws.count, 0, 2 * sizeof(int), stream));
         HIP_TRY(mpcb::launch_list_all(cold, B, stream));
         HIP_TRY(mpcb::launch_dense(h->ds, di, out, cold, dense_grid, stream));
         return 0;
     } else {
-        HIP_TRY(hipMemsetAsync(ws.count, 0, sizeof(int), stream));
+        HIP_TRY(hipMemsetAsync(ws.count, 0, 2 * sizeof(int), stream));
         HIP_TRY(mpcb::launch_zspace(h->ds, di, out, B, ws, stream));
+        HIP_TRY(mpcb::launch_zspace_wide(h->ds, di, out, B < WIDE_GRID ? B : WIDE_GRID, ws, stream));
     }
     HIP_TRY(mpcb::launch_dense(h->ds, di, out, ws, dense_grid, stream));
     return 0;
@@ -453,6 +472,7 @@ void mpcb_destroy(mpcb_handle h) {
         }
         for (void *p : h->dev_allocs) (void)hipFree(p);
         if (h->ws.list) (void)hipFree(h->ws.list);
+        if (h->ws.wide_list) (void)hipFree(h->ws.wide_list);
         if (h->ws.warm_i) (void)hipFree(h->ws.warm_i);
         if (h->ws.warm_d) (void)hipFree(h->ws.warm_d);
         if (h->ws.J) (void)hipFree(h->ws.J);
@@ -472,6 +492,16 @@ int mpcb_debug_set_stamp_buffer(mpcb_handle h, long long *dev) {
     if (!h) return MPCB_E_ARG;
     h->ds.dbg = dev;
     return 0;
+}
+
+int mpcb_last_wide_count(mpcb_handle h) {
+    if (!h) return fail(MPCB_E_ARG, "null handle");
+    if (!h->ws.wide_count || !h->ws.wide_list) return 0;
+    DeviceGuard guard(h->params.device);
+    int n = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&n, h->ws.wide_count, sizeof(int), hipMemcpyDeviceToHost));
+    return n;
 }
 
 int mpcb_last_handover_count(mpcb_handle h) {
@@ -573,7 +603,9 @@ int mpcb_solve_coupled_device_noalloc(mpcb_handle h, int32_t B, const mpcb_coupl
     unsigned char *ptr = g_scratch[h->params.device];
     mpcb::DenseWs ws = h->ws;
     ws.count = reinterpret_cast<int *>(ptr);
+    ws.wide_count = ws.count + 1;
     ws.list = reinterpret_cast<int *>(ptr + SCRATCH_LIST_OFF);
+    ws.wide_list = h->wide_fits ? reinterpret_cast<int *>(ptr + SCRATCH_WIDE_OFF) : nullptr;
     ws.J = reinterpret_cast<double *>(ptr + SCRATCH_J_OFF);
     ws.R = reinterpret_cast<double *>(ptr + SCRATCH_R_OFF);
     const int cap = h->dense_in_lds ? 512 : NOALLOC_SLOTS;

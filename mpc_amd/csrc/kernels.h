@@ -11,6 +11,9 @@ namespace mpcb {
 // numerically singular).  Such instances are re-solved by the dense kernel; the
 // value never leaves the library.
 constexpr int STATUS_UNRESOLVED = 3;
+// Internal as well: the first edition of the wave-per-QP kernel ran out of rows for the working
+// set and leaves the instance to its wide edition.
+constexpr int STATUS_TO_WIDE = 4;
 
 struct DevSetup {
     int N, m, axes, form;
@@ -66,6 +69,8 @@ constexpr int WARM_F = 32, WARM_FALG = 33, WARM_RNORM = 34;
 struct DenseWs {
     int *list;                 // instance indices the first stage could not certify
     int *count;                // how many
+    int *wide_list;            // coupled forms: instances the first edition of the wave-per-QP kernel
+    int *wide_count;           //   leaves to its wide edition (working set beyond 32 rows), or NULL
     int *warm_i;               // [B][WARM_STRIDE] hand-over records (see above), or NULL
     double *warm_d;            // [B][WARM_STRIDE]
     double *J, *R;             // workspace: one n x n slot of each per resident workgroup
@@ -79,6 +84,13 @@ struct DenseWs {
 // cannot certify are appended to ws.list (ws.count must be zero on entry).
 hipError_t launch_zspace(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
                          const DenseWs &ws, hipStream_t stream);
+
+// Enqueues the wide edition (60-row capacity, a quarter of the occupancy) over ws.wide_list with
+// `blocks` single-wave workgroups; what it cannot finish either joins ws.list.  A no-op for box
+// problems and when ws.wide_list is NULL.  LDS bytes one of its workgroups needs.
+hipError_t launch_zspace_wide(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int blocks,
+                              const DenseWs &ws, hipStream_t stream);
+size_t zspace_wide_lds_bytes(const DevSetup &sd);
 
 // Fills ws.list with 0..B-1 and ws.count with B (dense-only mode).
 hipError_t launch_list_all(const DenseWs &ws, int B, hipStream_t stream);

@@ -61,12 +61,15 @@ struct WaveStateT {
     int oldRow[QL + 1], oldKS[QL + 1];
     int pad; // (4 QL + 9 ints above: an odd number)
 };
-template <bool POLY, int NPL>
+// WIDE: the second edition of this kernel, which takes over the instances whose working set
+// outgrows the 32 rows (coupled forms): 60 rows -- with the four padding entries that is one lane
+// per working-set position -- at a quarter of the occupancy (38 KB of LDS per wave).
+template <bool POLY, int NPL, bool WIDE>
 struct WaveConfig {
-    static constexpr int QL = 32;
+    static constexpr int QL = WIDE ? 60 : 32;
     typedef WaveStateT<QL, !POLY> State;
-    static_assert(QL <= WARM_QL, "a hand-over record holds the whole working set");
-    static_assert(QL <= 64 && QL % 4 == 0, "one lane per working-set position; products run four terms per trip");
+    static_assert(POLY || QL <= WARM_QL, "a hand-over record holds the whole working set");
+    static_assert(QL + 4 <= 64 && QL % 4 == 0, "one lane per working-set position; products run four terms per trip");
     static_assert(sizeof(State) % 8 == 0, "tab must stay 8-byte aligned");
 };
 
@@ -265,18 +268,17 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
 // HV: every instance has its own CoM height (in.height): the response tables are combined from
 // their height-free parts as they are read, S = Spp - c Sps + c^2 Saa, W^T = Wtp - c Wta,
 // Kz = Kzp - c Kza with c = height / gravity (three loads per entry instead of one).
-template <int NPL, bool POLY, bool ROWS, bool HV>
-__global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
-                                                      int *unresolved_list, int *unresolved_count,
-                                                      int *warm_i, double *warm_d) {
+// One QP, solved by the calling wave in its LDS slice `smem` (see the head of the file).
+// Instances this edition cannot finish are appended to wide_list (capacity reached and a wide
+// edition follows) or to unresolved_list (for the dense kernel).
+template <int NPL, bool POLY, bool ROWS, bool HV, bool WIDE>
+__device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out,
+                                               const int inst, const int lane, double *smem, int *unresolved_list,
+                                               int *unresolved_count, int *warm_i, double *warm_d, int *wide_list,
+                                               int *wide_count) {
     constexpr int ES = POLY ? 4 : 2;
-    typedef typename WaveConfig<POLY, NPL>::State WaveState;
+    typedef typename WaveConfig<POLY, NPL, WIDE>::State WaveState;
     constexpr int QL = WaveState::QL, LDI = WaveState::LDI;
-    extern __shared__ double smem[];
-    const int lane = threadIdx.x & 63;
-    const int wv = ufirst((int)(threadIdx.x >> 6));
-    const int inst = ufirst((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (inst >= B) return;
     const int N = sd.N;
 #ifdef MPCB_STAMPS
     long long stamp_acc[16] = {0};
@@ -284,9 +286,8 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
 #endif
     // polygon table (one padding phase after the last) + the ZMP reference per segment
     const int tab_doubles = POLY ? (sd.nphase + 1) * 12 + 2 * max(sd.nphase, sd.nref) : 0;
-    const int per_wave = (int)(sizeof(WaveState) / 8) + tab_doubles;
-    WaveState &W = *reinterpret_cast<WaveState *>(smem + (size_t)wv * per_wave);
-    double *tab = smem + (size_t)wv * per_wave + sizeof(WaveState) / 8; // [phase][edge][p,q,r]
+    WaveState &W = *reinterpret_cast<WaveState *>(smem);
+    double *tab = smem + sizeof(WaveState) / 8; // [phase][edge][p,q,r]
     double *cref = tab + (POLY ? (sd.nphase + 1) * 12 : 0);              // [phase][x,y] ZMP reference
 
     // ---- owned knots ------------------------------------------------------
@@ -970,7 +971,8 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
                 ucand = ufirst(ucand + t);
                 if (t == t2) { // full step: add the constraint (:392-426, add_constraint :450-513)
                     if (iq >= (POLY ? QL : QL_BOX)) {
-                        status = STATUS_UNRESOLVED;
+                        // (a wide edition, where one follows, takes the instances that are merely too big)
+                        status = (!WIDE && wide_list) ? STATUS_TO_WIDE : STATUS_UNRESOLVED;
                         done = true;
                         break;
                     }
@@ -1067,6 +1069,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
     const bool solved = status == MPCB_OK || status == MPCB_ITER_CAP;
     if (status == STATUS_UNRESOLVED && lane_e == 0 && unresolved_list)
         unresolved_list[atomicAdd(unresolved_count, 1)] = inst_e; // re-solved by the dense kernel
+    if (status == STATUS_TO_WIDE && lane_e == 0) wide_list[atomicAdd(wide_count, 1)] = inst_e;
     if (status == STATUS_UNRESOLVED && warm_i) {
         // where the dense kernel takes over: the top of this outer iteration
         int *wi = warm_i + (size_t)inst_e * WARM_STRIDE;
@@ -1254,25 +1257,70 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
 #endif
 }
 
+// First edition: one QP per single-wave workgroup, instance = workgroup index.
+template <int NPL, bool POLY, bool ROWS, bool HV>
+__global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
+                                                      int *unresolved_list, int *unresolved_count,
+                                                      int *warm_i, double *warm_d, int *wide_list,
+                                                      int *wide_count) {
+    extern __shared__ double smem[];
+    const int inst = ufirst((int)blockIdx.x);
+    if (inst >= B) return;
+    solve_instance<NPL, POLY, ROWS, HV, false>(sd, in, out, inst, (int)(threadIdx.x & 63), smem, unresolved_list,
+                                               unresolved_count, warm_i, warm_d, wide_list, wide_count);
+}
+
+// Wide edition: the workgroups (single waves again) share out the list the first edition left.
+template <int NPL, bool ROWS, bool HV>
+__global__ __launch_bounds__(64, 1) void zspace_wide_kernel(DevSetup sd, DevIn in, mpcb_outputs out,
+                                                            const int *work_list, const int *work_count,
+                                                            int *unresolved_list, int *unresolved_count) {
+    extern __shared__ double smem[];
+    const int count = ufirst(*work_count);
+    for (int entry = blockIdx.x; entry < count; entry += gridDim.x) {
+        solve_instance<NPL, true, ROWS, HV, true>(sd, in, out, ufirst(work_list[entry]), (int)(threadIdx.x & 63), smem,
+                                                  unresolved_list, unresolved_count, nullptr, nullptr, nullptr,
+                                                  nullptr);
+        wsync();
+    }
+}
+
+template <bool POLY, int NPL, bool WIDE>
+size_t wave_lds_bytes(const DevSetup &sd) {
+    return sizeof(typename WaveConfig<POLY, NPL, WIDE>::State) +
+           (POLY ? ((size_t)(sd.nphase + 1) * 12 + 2 * (size_t)std::max(sd.nphase, sd.nref)) * 8 : 0);
+}
+
 template <int NPL, bool POLY, bool ROWS, bool HV>
 hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
                       const DenseWs &ws, hipStream_t stream) {
-    const size_t per_wave = sizeof(typename WaveConfig<POLY, NPL>::State) +
-                            (POLY ? ((size_t)(sd.nphase + 1) * 12 + 2 * (size_t)std::max(sd.nphase, sd.nref)) * 8 : 0);
     // One wave (= one QP) per workgroup: waves never wait for each other, so a workgroup's LDS
     // and wave slot are released the moment its QP is done instead of when the slowest of
     // several is (iteration counts differ by 2-3x between instances).
-    const int wpb = 1;
-    size_t shmem = (size_t)wpb * per_wave;
+    const size_t shmem = wave_lds_bytes<POLY, NPL, false>(sd);
     auto kfn = zspace_kernel<NPL, POLY, ROWS, HV>;
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    const int blocks = (B + wpb - 1) / wpb;
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64 * wpb), shmem, stream, sd, in, out, B, ws.list, ws.count, ws.warm_i,
-                       ws.warm_d);
+    hipLaunchKernelGGL(kfn, dim3(B), dim3(64), shmem, stream, sd, in, out, B, ws.list, ws.count, ws.warm_i,
+                       ws.warm_d, POLY ? ws.wide_list : nullptr, ws.wide_count);
+    return hipGetLastError();
+}
+
+template <int NPL, bool ROWS, bool HV>
+hipError_t launch_one_wide(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int blocks,
+                           const DenseWs &ws, hipStream_t stream) {
+    const size_t shmem = wave_lds_bytes<true, NPL, true>(sd);
+    auto kfn = zspace_wide_kernel<NPL, ROWS, HV>;
+    if (shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64), shmem, stream, sd, in, out, ws.wide_list, ws.wide_count, ws.list,
+                       ws.count);
     return hipGetLastError();
 }
 
@@ -1283,6 +1331,15 @@ hipError_t launch_npl(const DevSetup &sd, const DevIn &in, const mpcb_outputs &o
     if (npl <= 2) return launch_one<2, POLY, ROWS, HV>(sd, in, out, B, ws, stream);
     if (npl <= 4) return launch_one<4, POLY, ROWS, HV>(sd, in, out, B, ws, stream);
     return launch_one<8, POLY, ROWS, HV>(sd, in, out, B, ws, stream);
+}
+
+template <bool ROWS, bool HV>
+hipError_t launch_npl_wide(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int blocks, const DenseWs &ws,
+                           hipStream_t stream) {
+    const int npl = (sd.N + 63) / 64;
+    if (npl <= 2) return launch_one_wide<2, ROWS, HV>(sd, in, out, blocks, ws, stream);
+    if (npl <= 4) return launch_one_wide<4, ROWS, HV>(sd, in, out, blocks, ws, stream);
+    return launch_one_wide<8, ROWS, HV>(sd, in, out, blocks, ws, stream);
 }
 
 } // namespace
@@ -1300,6 +1357,23 @@ hipError_t launch_zspace(const DevSetup &sd, const DevIn &in, const mpcb_outputs
     if (poly && in.rows_pqr) return launch_npl<true, true, false>(sd, in, out, B, ws, stream);
     if (poly) return launch_npl<true, false, false>(sd, in, out, B, ws, stream);
     return launch_npl<false, false, false>(sd, in, out, B, ws, stream);
+}
+
+hipError_t launch_zspace_wide(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int blocks,
+                              const DenseWs &ws, hipStream_t stream) {
+    if (blocks <= 0 || sd.form == MPCB_BOX_1D || !ws.wide_list) return hipSuccess;
+    if (in.height) {
+        if (in.rows_pqr) return launch_npl_wide<true, true>(sd, in, out, blocks, ws, stream);
+        return launch_npl_wide<false, true>(sd, in, out, blocks, ws, stream);
+    }
+    if (in.rows_pqr) return launch_npl_wide<true, false>(sd, in, out, blocks, ws, stream);
+    return launch_npl_wide<false, false>(sd, in, out, blocks, ws, stream);
+}
+
+size_t zspace_wide_lds_bytes(const DevSetup &sd) {
+    const int npl = (sd.N + 63) / 64;
+    return npl <= 2 ? wave_lds_bytes<true, 2, true>(sd) : npl <= 4 ? wave_lds_bytes<true, 4, true>(sd)
+                                                                   : wave_lds_bytes<true, 8, true>(sd);
 }
 
 } // namespace mpcb

@@ -23,7 +23,7 @@ MODE_AUTO, MODE_DENSE = 0, 1
 EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constraints", "mpcb_num_phases",
            "mpcb_solve_coupled_device", "mpcb_solve_coupled", "mpcb_solve_box_device",
            "mpcb_solve_box", "mpcb_get_matrix", "mpcb_replan_sweep_device",
-           "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained", "mpcb_last_handover_count",
+           "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained", "mpcb_last_handover_count", "mpcb_last_wide_count",
            "mpcb_solve_coupled_device_noalloc", "mpcb_solve_coupled_multi", "mpcb_debug_set_stamp_buffer")
 
 
@@ -84,6 +84,7 @@ def load_library():
                                               C.c_void_p, C.c_void_p, C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_get_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.mpcb_last_handover_count.argtypes = [C.c_void_p]
+        lib.mpcb_last_wide_count.argtypes = [C.c_void_p]
         lib.mpcb_solve_unconstrained_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                                         C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_replan_sweep_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -192,6 +193,11 @@ class BatchedPlanner:
         if stream is None:
             stream = self._torch.cuda.current_stream(self.device)
         return C.c_void_p(stream.cuda_stream)
+
+    def last_wide_count(self):
+        """Instances of the most recent coupled solve that the wide edition of the first-stage kernel took
+        over (working sets of 33 to 60 rows)."""
+        return _check(load_library().mpcb_last_wide_count(self._h))
 
     def last_handover_count(self):
         """Instances of the most recent solve that went through the dense second-stage kernel."""

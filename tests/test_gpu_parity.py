@@ -402,25 +402,34 @@ def test_dense_kernel_alone_vs_oracle(P, oracle):
         assert _rel(ob["jerk_x"][i], rb["jerk_x"][i]) < RTOL
 
 
-def test_large_working_sets_fall_back_to_dense(P, oracle):
-    """weight_R = 1e-6 (the constructor default, MPCPlanner.cpp:39): working sets of 20-45 rows
-    exceed the first stage's factor, so part of the batch goes through the dense kernel.
-    The Hessian's condition number is ~1e10 here: the reference's own double-precision
-    Cholesky is only good to ~1e-6 relative, so the tolerance is 1e-4."""
-    B, N, steps = 32, 200, 20
-    bt = batches.coupled_batch(B)
-    pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=1e-6, weight_Q=1.0, number_of_steps=steps)
-    o = _np(pl.solve_coupled(**bt))
-    ref = oracle.coupled_batch(oracle.params(N, R=1e-6, Q=1.0, height=0.5, iter_cap=4000), oracle.COUPLED_VEL,
-                               steps, 1000, bt["x0"], bt["y0"], bt["speed"], bt["feet_x"], bt["feet_y"],
-                               bt["swing0"], nthreads=16)
-    assert (o["status"] == ref["status"]).all() and (ref["n_active"] > 32).any()
-    for i in range(B):
-        na = ref["n_active"][i]
-        assert list(o["active_idx"][i, :na]) == list(ref["active"][i, :na])
-        for k in ("com_x", "com_y", "zmp_x", "zmp_y"):
-            assert _rel(o[k][i], ref[k][i]) < 1e-4
-    assert (np.abs(o["cost"] - ref["cost"]) <= 1e-4 * np.abs(ref["cost"])).all()
+def test_large_working_sets_wide_edition_and_dense_fallback(P, oracle):
+    """weight_R = 1e-6 (the constructor default, MPCPlanner.cpp:39): working sets of 20-53 rows
+    exceed the 32 rows of the first-stage kernel, so part of the batch is taken over by its wide
+    edition (60 rows); at weight_R = 1e-8 and three times the walking speed one working set reaches
+    74 rows and goes on to the dense kernel.  The Hessian's condition number is ~1e10 and more
+    here: the reference's own double-precision Cholesky is only good to ~1e-6 relative, so the
+    tolerance is 1e-4."""
+    N, steps = 200, 20
+    for B, R, speed_scale, beyond_wide in ((32, 1e-6, 1.0, False), (8, 1e-8, 3.0, True)):
+        bt = batches.coupled_batch(B)
+        bt["speed"] = bt["speed"] * speed_scale
+        pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=R, weight_Q=1.0, number_of_steps=steps)
+        o = _np(pl.solve_coupled(**bt))
+        ref = oracle.coupled_batch(oracle.params(N, R=R, Q=1.0, height=0.5, iter_cap=8000), oracle.COUPLED_VEL,
+                                   steps, 1000, bt["x0"], bt["y0"], bt["speed"], bt["feet_x"], bt["feet_y"],
+                                   bt["swing0"], nthreads=16)
+        assert (o["status"] == ref["status"]).all() and (ref["n_active"] > 32).any()
+        assert pl.last_wide_count() >= (ref["n_active"] > 32).sum()
+        assert (pl.last_handover_count() > 0) == beyond_wide == bool((ref["n_active"] > 60).any())
+        assert (o["iters"] == ref["iters"]).all()
+        for i in range(B):
+            na = ref["n_active"][i]
+            assert o["n_active"][i] == na
+            assert list(o["active_idx"][i, :min(na, o["active_idx"].shape[1])]) == \
+                list(ref["active"][i, :min(na, o["active_idx"].shape[1])])
+            for k in ("com_x", "com_y", "zmp_x", "zmp_y"):
+                assert _rel(o[k][i], ref[k][i]) < 1e-4
+        assert (np.abs(o["cost"] - ref["cost"]) <= 1e-4 * np.abs(ref["cost"])).all()
 
 
 def test_replanning_sweep_vs_oracle(P, oracle):

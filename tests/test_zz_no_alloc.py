@@ -1,7 +1,8 @@
 """The entry point that allocates nothing (static device scratch instead of the handle's
-hipMalloc'd hand-over list and dense workspace) returns, bit for bit, what
-mpcb_solve_coupled_device returns -- on two calls in a row, the second with a smaller batch,
-with instances going through the dense second stage (the scratch's J / R slots) in both."""
+hipMalloc'd lists and dense workspace) returns, bit for bit, what mpcb_solve_coupled_device
+returns -- on two calls in a row, the second with a smaller batch, with instances going through
+the wide edition of the first-stage kernel (the scratch's second list) and through the dense
+second stage (the scratch's J / R slots)."""
 import numpy as np
 import pytest
 
@@ -19,12 +20,12 @@ def P():
     return planner
 
 
-def _compare(P, pl, B, first, expect_handover):
+def _compare(P, pl, B, first, expect_handover, expect_wide=False):
     import torch
     bt = batches.coupled_batch(B, first=first)
     prepared = pl.prepare_coupled(**bt)
     ref = {k: v.cpu().numpy() for k, v in pl.solve_coupled_prepared(prepared).items()}
-    handed = pl.last_handover_count()
+    handed, wide = pl.last_handover_count(), pl.last_wide_count()
     out = pl._alloc_outputs(B, P.ALL_OUTPUTS)
     for t in out[0].values():  # whatever the call does not write must show up
         t.fill_(-7)
@@ -33,24 +34,29 @@ def _compare(P, pl, B, first, expect_handover):
     torch.cuda.synchronize()
     for k, v in ref.items():
         assert np.array_equal(got[k].cpu().numpy(), v, equal_nan=True), (B, k)
-    assert (handed > 0) == expect_handover
-    return handed
+    assert (handed > 0) == expect_handover and (wide > 0) == expect_wide
+    return handed + wide
 
 
 def test_no_alloc_entry_point_matches_allocating_one(P):
     N, steps = 200, 20
-    # weight_R = 1e-6: working sets beyond the first stage's capacity, so part of each batch is
-    # handed to the dense stage, whose J / R slots are the scratch's (8 of them: the first batch
-    # hands over more instances than that)
+    # weight_R = 1e-6: working sets of 33 to 53 rows, so part of each batch goes through the wide
+    # edition of the first-stage kernel, whose work list is the scratch's
     hard = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=1e-6, weight_Q=1.0, number_of_steps=steps)
-    h1 = _compare(P, hard, 40, 0, True)
-    h2 = _compare(P, hard, 12, 500, True)
+    h1 = _compare(P, hard, 40, 0, False, True)
+    h2 = _compare(P, hard, 12, 500, False, True)
     assert h1 > 8 and h2 >= 1
+    # every instance through the dense stage, whose J / R slots are the scratch's (8 of them: both
+    # batches hold more instances than that)
+    dense = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=steps,
+                             solver_mode=1)
+    assert _compare(P, dense, 24, 0, True) == 24
+    assert _compare(P, dense, 10, 300, True) == 10
     # the benchmark's weights: nothing is handed over, counter and list only
     easy = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
     _compare(P, easy, 96, 0, False)
     _compare(P, easy, 33, 96, False)
-    _compare(P, hard, 20, 900, True)  # and the first handle again, after another one used the scratch
+    _compare(P, hard, 20, 900, False, True)  # and the first handle again, after others used the scratch
 
 
 def test_no_alloc_entry_point_rejects_sizes_beyond_its_scratch(P):
