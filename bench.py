@@ -364,8 +364,8 @@ def main():
         wl.step()
     ev1.record()
     torch.cuda.synchronize()
+    t1 = time.perf_counter()  # this rank's K steps are done; the MAX over ranks below is the job's time
     barrier()
-    t1 = time.perf_counter()
     elapsed = t1 - t0
     dev_ms = ev0.elapsed_time(ev1)  # device time of the K steps on the launch stream
     if distributed:
