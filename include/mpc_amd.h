@@ -250,6 +250,22 @@ int  mpcb_last_handover_count(mpcb_handle h);
  * mpcb_last_handover_count.  Always 0 for box problems.  Waits for the device. */
 int  mpcb_last_wide_count(mpcb_handle h);
 
+/* Scheduling only, no counterpart in the reference (which solves one QP at a time): the order in
+ * which the first-stage kernel starts the instances of a batch.  Results do not depend on it.
+ * MPCB_DISPATCH_IN_ORDER (default): by instance index.  MPCB_DISPATCH_LONGEST_FIRST: every solve
+ * records the running time of each instance, and the next solve of the same batch size on
+ * this handle starts the instances that took longest first (index order when there is no such
+ * record).  A QP's running time spans a factor of two to three within a batch, so with a few
+ * instances per wave slot the launch otherwise ends waiting for long instances that started
+ * late; callers that solve a slowly changing batch again and again (a receding-horizon loop)
+ * gain 10-25 %, unrelated batches gain nothing and lose nothing.  Costs 2 x (256 + B) + B ints of
+ * device memory, allocated by the next solve.  In mpcb_replan_sweep_device every stage is ordered
+ * by the stage before it (of no use when a stage advances a whole footstep: the running times
+ * of consecutive stages are then unrelated).  The _noalloc entry point always runs in index
+ * order. */
+enum { MPCB_DISPATCH_IN_ORDER = 0, MPCB_DISPATCH_LONGEST_FIRST = 1 };
+int  mpcb_set_dispatch_hint(mpcb_handle h, int32_t mode);
+
 /* Diagnostic builds only (library compiled with -DMPCB_STAMPS): device buffer of 16 cycle
  * counters per instance that the kernels fill; a no-op pointer store in the normal build. */
 int  mpcb_debug_set_stamp_buffer(mpcb_handle h, long long *dev);

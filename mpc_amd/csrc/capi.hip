@@ -68,6 +68,13 @@ struct mpcb_handle_s {
     int slot_target = 16;    // slots wanted: raised to the largest hand-over count seen (<= 512)
     bool dense_in_lds = false; // the dense kernel keeps J and R in LDS: no HBM slots at all
     bool wide_fits = false;    // the wide edition of the first-stage kernel fits the LDS for this shape
+    // longest-first dispatch of the first stage (mpcb_set_dispatch_hint): the permutation and the
+    // two records (previous solve / this solve) it is built from, swapped after every solve
+    int dispatch_hint = MPCB_DISPATCH_IN_ORDER;
+    int *order = nullptr;
+    int *order_rec[2] = {nullptr, nullptr};
+    int order_capacity = 0;
+    int order_parity = 0;
     std::vector<void *> dev_allocs;   // tables: freed by mpcb_destroy only
     // hand-over count of the latest solve, copied to page-locked host memory behind the kernels;
     // read (without waiting) at the start of the next solve to size the dense workspace
@@ -277,7 +284,7 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
     }
     {
         int *cnt = nullptr;
-        if (hipMalloc((void **)&cnt, 2 * sizeof(int)) != hipSuccess) { // hand-overs to the dense kernel, to the wide edition
+        if (hipMalloc((void **)&cnt, mpcb::COUNTER_INTS * sizeof(int)) != hipSuccess) { // hand-overs to the dense kernel, to the wide edition
             mpcb_destroy(h);
             return fail(MPCB_E_HIP, "hipMalloc failed");
         }
@@ -316,6 +323,16 @@ namespace {
 // earlier solve of this handle reported (the kernel loops over the list with as many workgroups
 // as there are slots, so fewer slots than hand-overs is slower, never wrong).  Superseded
 // buffers are freed here, after the stream has drained.
+void release_order_buffers(mpcb_handle h) {
+    if (h->order) (void)hipFree(h->order);
+    for (int r = 0; r < 2; r++) {
+        if (h->order_rec[r]) (void)hipFree(h->order_rec[r]);
+        h->order_rec[r] = nullptr;
+    }
+    h->order = nullptr;
+    h->order_capacity = 0;
+}
+
 int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
     if (h->count_pending && hipEventQuery(h->count_event) == hipSuccess) {
         h->count_pending = false;
@@ -344,6 +361,18 @@ int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
             HIP_TRY(hipMalloc((void **)&h->ws.warm_d, (size_t)cap * mpcb::WARM_STRIDE * sizeof(double)));
         }
         h->list_capacity = cap;
+    }
+    if (h->dispatch_hint != MPCB_DISPATCH_IN_ORDER && h->order_capacity < h->list_capacity) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        release_order_buffers(h);
+        const size_t cap = (size_t)h->list_capacity;
+        HIP_TRY(hipMalloc((void **)&h->order, cap * sizeof(int)));
+        for (int r = 0; r < 2; r++) {
+            HIP_TRY(hipMalloc((void **)&h->order_rec[r], (mpcb::ORDER_BINS + cap) * sizeof(int)));
+            // an all-zero histogram is "no record": the first solve runs in index order
+            HIP_TRY(hipMemsetAsync(h->order_rec[r], 0, mpcb::ORDER_BINS * sizeof(int), stream));
+        }
+        h->order_capacity = (int)cap;
     }
     if (h->dense_in_lds) return 0;
     int want = h->params.solver_mode == MPCB_MODE_DENSE ? 512 : h->slot_target;
@@ -419,7 +448,8 @@ int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &o
         ds.F2 = h->knot_F2;
         ds.F3 = h->knot_F3;
         ds.nref = ds.N;
-        HIP_TRY(hipMemsetAsync(ws.count, 0, 2 * sizeof(int), stream));
+        if (ws.order) HIP_TRY(mpcb::launch_dispatch_order(ws, B, stream));
+        else HIP_TRY(hipMemsetAsync(ws.count, 0, mpcb::COUNTER_INTS * sizeof(int), stream));
         if (h->params.solver_mode == MPCB_MODE_DENSE) {
             HIP_TRY(mpcb::launch_list_all(ws, B, stream));
         } else {
@@ -435,12 +465,13 @@ int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &o
         mpcb::DenseWs cold = ws;
         cold.warm_i = nullptr;
         cold.warm_d = nullptr;
-        HIP_TRY(hipMemsetAsync(ws.count, 0, 2 * sizeof(int), stream));
+        HIP_TRY(hipMemsetAsync(ws.count, 0, mpcb::COUNTER_INTS * sizeof(int), stream));
         HIP_TRY(mpcb::launch_list_all(cold, B, stream));
         HIP_TRY(mpcb::launch_dense(h->ds, di, out, cold, dense_grid, stream));
         return 0;
     } else {
-        HIP_TRY(hipMemsetAsync(ws.count, 0, 2 * sizeof(int), stream));
+        if (ws.order) HIP_TRY(mpcb::launch_dispatch_order(ws, B, stream));
+        else HIP_TRY(hipMemsetAsync(ws.count, 0, mpcb::COUNTER_INTS * sizeof(int), stream));
         HIP_TRY(mpcb::launch_zspace(h->ds, di, out, B, ws, stream));
         HIP_TRY(mpcb::launch_zspace_wide(h->ds, di, out, B < WIDE_GRID ? B : WIDE_GRID, ws, stream));
     }
@@ -448,12 +479,24 @@ int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &o
     return 0;
 }
 
+bool first_stage_runs(mpcb_handle h) {
+    return h->params.solver_mode != MPCB_MODE_DENSE && h->params.formulation != MPCB_BOX_SLACK &&
+           h->params.formulation != MPCB_UNCONSTRAINED;
+}
+
 int solve_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &out, int B, hipStream_t stream) {
     if (B == 0) return 0;
     int rc = ensure_workspace(h, B, stream);
     if (rc) return rc;
     const int cap = h->dense_in_lds ? 512 : h->dense_slots;
-    if ((rc = launch_two_stage(h, di, out, B, h->ws, B < cap ? B : cap, stream))) return rc;
+    mpcb::DenseWs ws = h->ws;
+    if (h->dispatch_hint != MPCB_DISPATCH_IN_ORDER && first_stage_runs(h)) {
+        ws.order = h->order;
+        ws.order_prev = h->order_rec[h->order_parity ^ 1];
+        ws.order_record = h->order_rec[h->order_parity];
+        h->order_parity ^= 1;
+    }
+    if ((rc = launch_two_stage(h, di, out, B, ws, B < cap ? B : cap, stream))) return rc;
     HIP_TRY(hipMemcpyAsync(h->count_host, h->ws.count, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(h->count_event, stream));
     h->count_pending = true;
@@ -477,6 +520,7 @@ void mpcb_destroy(mpcb_handle h) {
         if (h->ws.warm_d) (void)hipFree(h->ws.warm_d);
         if (h->ws.J) (void)hipFree(h->ws.J);
         if (h->ws.R) (void)hipFree(h->ws.R);
+        release_order_buffers(h);
         if (h->stage_dev) (void)hipFree(h->stage_dev);
         if (h->count_event) (void)hipEventDestroy(h->count_event);
         if (h->count_host) (void)hipHostFree(h->count_host);
@@ -491,6 +535,14 @@ int mpcb_num_phases(mpcb_handle h) { return h ? h->hs.nphase : MPCB_E_ARG; }
 int mpcb_debug_set_stamp_buffer(mpcb_handle h, long long *dev) {
     if (!h) return MPCB_E_ARG;
     h->ds.dbg = dev;
+    return 0;
+}
+
+int mpcb_set_dispatch_hint(mpcb_handle h, int32_t mode) {
+    if (!h) return fail(MPCB_E_ARG, "null handle");
+    if (mode != MPCB_DISPATCH_IN_ORDER && mode != MPCB_DISPATCH_LONGEST_FIRST)
+        return fail(MPCB_E_ARG, "unknown dispatch hint");
+    h->dispatch_hint = mode;
     return 0;
 }
 
@@ -602,6 +654,9 @@ int mpcb_solve_coupled_device_noalloc(mpcb_handle h, int32_t B, const mpcb_coupl
     // the handle's tables with this device's static scratch in place of the allocated workspace
     unsigned char *ptr = g_scratch[h->params.device];
     mpcb::DenseWs ws = h->ws;
+    ws.order = nullptr; // index order: the order buffers belong to the allocating entry points
+    ws.order_prev = nullptr;
+    ws.order_record = nullptr;
     ws.count = reinterpret_cast<int *>(ptr);
     ws.wide_count = ws.count + 1;
     ws.list = reinterpret_cast<int *>(ptr + SCRATCH_LIST_OFF);

@@ -270,13 +270,17 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
 // Kz = Kzp - c Kza with c = height / gravity (three loads per entry instead of one).
 // One QP, solved by the calling wave in its LDS slice `smem` (see the head of the file).
 // Instances this edition cannot finish are appended to wide_list (capacity reached and a wide
-// edition follows) or to unresolved_list (for the dense kernel).
+// edition follows) or to unresolved_list (for the dense kernel).  The first edition also notes how
+// long the instance took in the record whose address follows the two counters at
+// unresolved_count, if there is one (see dispatch_order_kernel).
 template <int NPL, bool POLY, bool ROWS, bool HV, bool WIDE>
 __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out,
                                                const int inst, const int lane, double *smem, int *unresolved_list,
                                                int *unresolved_count, int *warm_i, double *warm_d, int *wide_list,
                                                int *wide_count) {
     constexpr int ES = POLY ? 4 : 2;
+    unsigned t_start = 0;
+    if constexpr (!WIDE) t_start = (unsigned)__builtin_amdgcn_s_memtime(); // for the dispatch-order record
     typedef typename WaveConfig<POLY, NPL, WIDE>::State WaveState;
     constexpr int QL = WaveState::QL, LDI = WaveState::LDI;
     const int N = sd.N;
@@ -554,7 +558,10 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
     // not exist; clamp so the (masked) read stays inside the instance's rows
     const double *rows = ROWS ? in.rows_pqr + (size_t)inst * sd.m * 3 : nullptr;
     auto rowIdx = [&](int c, int e) -> int {
-        const int r = ROW0(c) + e;
+        // (recomputed at every use: the twelve sums would otherwise stay in registers throughout)
+        int packed = phr[c];
+        asm volatile("" : "+v"(packed));
+        const int r = (packed >> 10) + e;
         return r < sd.m ? r : sd.m - 1;
     };
     auto slotP = [&](int c, int e) -> double {
@@ -1070,6 +1077,20 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
     if (status == STATUS_UNRESOLVED && lane_e == 0 && unresolved_list)
         unresolved_list[atomicAdd(unresolved_count, 1)] = inst_e; // re-solved by the dense kernel
     if (status == STATUS_TO_WIDE && lane_e == 0) wide_list[atomicAdd(wide_count, 1)] = inst_e;
+    if constexpr (!WIDE) {
+        int *order_record = *reinterpret_cast<int *const *>(unresolved_count + 2);
+        if (order_record && lane_e == 0) {
+            // bin = running time on a logarithmic scale, 16 bins to the octave (hand-overs count as
+            // the longest); key = bin | rank within the bin << 8
+            unsigned dt = (unsigned)__builtin_amdgcn_s_memtime() - t_start;
+            dt = dt < 16u ? 16u : dt;
+            const int oct = 31 - __builtin_clz(dt);
+            int bin = (oct - 4) * 16 + (int)((dt >> (oct - 4)) & 15u);
+            bin = bin < ORDER_BINS - 2 ? bin : ORDER_BINS - 2;
+            if (status == STATUS_UNRESOLVED || status == STATUS_TO_WIDE) bin = ORDER_BINS - 1;
+            order_record[ORDER_BINS + inst_e] = bin | (atomicAdd(order_record + bin, 1) << 8);
+        }
+    }
     if (status == STATUS_UNRESOLVED && warm_i) {
         // where the dense kernel takes over: the top of this outer iteration
         int *wi = warm_i + (size_t)inst_e * WARM_STRIDE;
@@ -1262,12 +1283,55 @@ template <int NPL, bool POLY, bool ROWS, bool HV>
 __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
                                                       int *unresolved_list, int *unresolved_count,
                                                       int *warm_i, double *warm_d, int *wide_list,
-                                                      int *wide_count) {
+                                                      int *wide_count, const int *order) {
     extern __shared__ double smem[];
-    const int inst = ufirst((int)blockIdx.x);
-    if (inst >= B) return;
+    if ((int)blockIdx.x >= B) return;
+    const int inst = ufirst(order ? order[blockIdx.x] : (int)blockIdx.x);
     solve_instance<NPL, POLY, ROWS, HV, false>(sd, in, out, inst, (int)(threadIdx.x & 63), smem, unresolved_list,
                                                unresolved_count, warm_i, warm_d, wide_list, wide_count);
+}
+
+// Longest first.  The hardware hands workgroups to free wave slots in index order, and a QP
+// takes between half and twice the average time, so with only a few QPs per slot the launch
+// ends with most slots idle while the last-started long ones finish.  When the previous solve of
+// the same batch size left a record -- prev[0..ORDER_BINS) counts per bin of running time,
+// prev[ORDER_BINS + i] = bin | rank << 8 of instance i -- this kernel turns it into the
+// permutation that starts the instances of the highest bin first (a counting sort: position =
+// instances in higher bins + rank).  Without a matching record the order is the identity.  It also
+// clears the histogram the coming solve accumulates into and the two hand-over counters, and leaves
+// the address of the coming solve's record behind them.
+__global__ __launch_bounds__(ORDER_BINS) void dispatch_order_kernel(const int *prev, int *next, int *order,
+                                                                    int *counts, int B) {
+    __shared__ int above[ORDER_BINS];
+    const int t = threadIdx.x;
+    const int mine = prev[t];
+    above[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < ORDER_BINS; off <<= 1) { // inclusive suffix sums
+        const int v = t + off < ORDER_BINS ? above[t + off] : 0;
+        __syncthreads();
+        above[t] += v;
+        __syncthreads();
+    }
+    const int total = above[0];
+    __syncthreads();
+    above[t] -= mine;
+    __syncthreads();
+    const int i = blockIdx.x * ORDER_BINS + t;
+    if (i < B) {
+        int pos = i;
+        if (total == B) {
+            const int key = prev[ORDER_BINS + i];
+            // (within a bin in reverse order of completion: the later, the longer)
+            pos = above[key & (ORDER_BINS - 1)] + (prev[key & (ORDER_BINS - 1)] - 1 - (key >> 8));
+        }
+        if (pos >= 0 && pos < B) order[pos] = total == B ? i : pos;
+    }
+    if (blockIdx.x == 0) {
+        next[t] = 0;
+        if (t < 2) counts[t] = 0;
+        if (t == 2) *reinterpret_cast<int **>(counts + 2) = next;
+    }
 }
 
 // Wide edition: the workgroups (single waves again) share out the list the first edition left.
@@ -1305,7 +1369,7 @@ hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &o
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kfn, dim3(B), dim3(64), shmem, stream, sd, in, out, B, ws.list, ws.count, ws.warm_i,
-                       ws.warm_d, POLY ? ws.wide_list : nullptr, ws.wide_count);
+                       ws.warm_d, POLY ? ws.wide_list : nullptr, ws.wide_count, ws.order);
     return hipGetLastError();
 }
 
@@ -1357,6 +1421,13 @@ hipError_t launch_zspace(const DevSetup &sd, const DevIn &in, const mpcb_outputs
     if (poly && in.rows_pqr) return launch_npl<true, true, false>(sd, in, out, B, ws, stream);
     if (poly) return launch_npl<true, false, false>(sd, in, out, B, ws, stream);
     return launch_npl<false, false, false>(sd, in, out, B, ws, stream);
+}
+
+hipError_t launch_dispatch_order(const DenseWs &ws, int B, hipStream_t stream) {
+    if (B <= 0 || !ws.order || !ws.order_prev || !ws.order_record) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dispatch_order_kernel, dim3((B + ORDER_BINS - 1) / ORDER_BINS), dim3(ORDER_BINS), 0, stream,
+                       ws.order_prev, ws.order_record, ws.order, ws.count, B);
+    return hipGetLastError();
 }
 
 hipError_t launch_zspace_wide(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int blocks,

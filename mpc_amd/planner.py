@@ -18,13 +18,15 @@ LIB_PATH = os.environ.get("MPC_AMD_LIB") or os.path.join(_HERE, "libmpc_amd.so")
 BOX_1D, COUPLED_JERK, COUPLED_VEL, COUPLED_REF, UNCONSTRAINED, BOX_SLACK = 0, 1, 2, 3, 4, 5
 OK, INFEASIBLE, ITER_CAP = 0, 1, 2
 MODE_AUTO, MODE_DENSE = 0, 1
+DISPATCH_IN_ORDER, DISPATCH_LONGEST_FIRST = 0, 1
 
 # every symbol include/mpc_amd.h declares
 EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constraints", "mpcb_num_phases",
            "mpcb_solve_coupled_device", "mpcb_solve_coupled", "mpcb_solve_box_device",
            "mpcb_solve_box", "mpcb_get_matrix", "mpcb_replan_sweep_device",
            "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained", "mpcb_last_handover_count", "mpcb_last_wide_count",
-           "mpcb_solve_coupled_device_noalloc", "mpcb_solve_coupled_multi", "mpcb_debug_set_stamp_buffer")
+           "mpcb_solve_coupled_device_noalloc", "mpcb_solve_coupled_multi", "mpcb_debug_set_stamp_buffer",
+           "mpcb_set_dispatch_hint")
 
 
 class Params(C.Structure):
@@ -85,6 +87,7 @@ def load_library():
         lib.mpcb_get_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.mpcb_last_handover_count.argtypes = [C.c_void_p]
         lib.mpcb_last_wide_count.argtypes = [C.c_void_p]
+        lib.mpcb_set_dispatch_hint.argtypes = [C.c_void_p, C.c_int32]
         lib.mpcb_solve_unconstrained_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                                         C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_replan_sweep_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -193,6 +196,12 @@ class BatchedPlanner:
         if stream is None:
             stream = self._torch.cuda.current_stream(self.device)
         return C.c_void_p(stream.cuda_stream)
+
+    def set_dispatch_hint(self, mode):
+        """DISPATCH_IN_ORDER (default) or DISPATCH_LONGEST_FIRST: start the instances of the next
+        solves in decreasing order of the iteration counts the solve before recorded (scheduling
+        only: results do not change)."""
+        _check(load_library().mpcb_set_dispatch_hint(self._h, int(mode)))
 
     def last_wide_count(self):
         """Instances of the most recent coupled solve that the wide edition of the first-stage kernel took

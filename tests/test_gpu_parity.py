@@ -886,3 +886,58 @@ def test_zmp_reference_per_knot_vs_oracle(P, oracle):
     with pytest.raises(P.MpcError, match="COUPLED_REF"):
         P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, number_of_steps=steps).solve_coupled(
             zref_knot=zk, **bt)
+
+
+def test_dispatch_hint_reorders_the_launch_not_the_results(P):
+    """mpcb_set_dispatch_hint(LONGEST_FIRST): the first stage starts the instances in the order of
+    the record the previous solve left.  Whatever that record is -- none, one of another batch,
+    one of another batch size, one with hand-overs -- every instance is solved exactly once and
+    every output is bit-identical to the index-order solve."""
+    import torch
+
+    def run(pl, prepare, solve, cases):
+        plain = []
+        for c in cases:
+            plain.append({k: v.cpu().numpy() for k, v in solve(prepare(c)).items()})
+        pl.set_dispatch_hint(P.DISPATCH_LONGEST_FIRST)
+        for rounds in range(2):  # second round: each case ordered by the record of the one before
+            for c, ref in zip(cases, plain):
+                prepared = prepare(c)
+                B = next(iter(ref.values())).shape[0]
+                out = pl._alloc_outputs(B, P.ALL_OUTPUTS)
+                for t in out[0].values():  # an instance the permutation skipped would show
+                    t.fill_(-7)
+                torch.cuda.synchronize()
+                got = solve(prepared, out=out)
+                torch.cuda.synchronize()
+                for k, v in ref.items():
+                    assert np.array_equal(got[k].cpu().numpy(), v, equal_nan=True), (c, k, rounds)
+        pl.set_dispatch_hint(P.DISPATCH_IN_ORDER)
+        c, ref = cases[0], plain[0]
+        got = solve(prepare(c))
+        for k, v in ref.items():
+            assert np.array_equal(got[k].cpu().numpy(), v, equal_nan=True), (c, k, "in order again")
+
+    N, steps = 200, 20
+    # (batch size, first instance): same size twice with different instances, a batch of 2,500
+    # (more than one workgroup of the ordering kernel, not a multiple of its 256 threads), a
+    # smaller one after it, a single instance
+    cases = [(700, 0), (700, 5000), (2500, 100), (333, 40), (1, 9)]
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
+    run(pl, lambda c: pl.prepare_coupled(**batches.coupled_batch(c[0], first=c[1])),
+        lambda prepared, out=None: pl.solve_coupled_prepared(prepared, out=out), cases)
+    # working sets of 33 to 53 rows: part of every batch goes on to the wide edition (the longest bin)
+    hard = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=1e-6, weight_Q=1.0, number_of_steps=steps)
+    run(hard, lambda c: hard.prepare_coupled(**batches.coupled_batch(c[0], first=c[1])),
+        lambda prepared, out=None: hard.solve_coupled_prepared(prepared, out=out), [(48, 0), (48, 300), (20, 7)])
+    assert hard.last_wide_count() > 0
+    # box form: the dense second stage takes over mid-solve from the records of the first
+    box = P.BatchedPlanner(100, formulation=P.BOX_1D, weight_R=1.0)
+
+    def prepare_box(c):
+        bt = batches.decoupled_batch(c[0], first=c[1])
+        return box.prepare_box(bt["x0"], bt["xmin"], bt["xmax"])
+
+    run(box, prepare_box, lambda prepared, out=None: box.solve_box_prepared(prepared, out=out),
+        [(600, 0), (600, 2000), (90, 11)])
+    assert box.last_handover_count() > 0
