@@ -258,7 +258,7 @@ int  mpcb_last_wide_count(mpcb_handle h);
  * record).  A QP's running time spans a factor of two to three within a batch, so with a few
  * instances per wave slot the launch otherwise ends waiting for long instances that started
  * late; callers that solve a slowly changing batch again and again (a receding-horizon loop)
- * gain 10-25 %, unrelated batches gain nothing and lose nothing.  Costs 2 x (256 + B) + B ints of
+ * gain 10-25 %, unrelated batches gain nothing and lose nothing.  Costs 2 B ints of
  * device memory, allocated by the next solve.  In mpcb_replan_sweep_device every stage is ordered
  * by the stage before it (of no use when a stage advances a whole footstep: the running times
  * of consecutive stages are then unrelated).  The _noalloc entry point always runs in index

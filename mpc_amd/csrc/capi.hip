@@ -69,12 +69,11 @@ struct mpcb_handle_s {
     bool dense_in_lds = false; // the dense kernel keeps J and R in LDS: no HBM slots at all
     bool wide_fits = false;    // the wide edition of the first-stage kernel fits the LDS for this shape
     // longest-first dispatch of the first stage (mpcb_set_dispatch_hint): the permutation and the
-    // two records (previous solve / this solve) it is built from, swapped after every solve
+    // running-time record it is built from
     int dispatch_hint = MPCB_DISPATCH_IN_ORDER;
     int *order = nullptr;
-    int *order_rec[2] = {nullptr, nullptr};
+    int *order_rec = nullptr;
     int order_capacity = 0;
-    int order_parity = 0;
     std::vector<void *> dev_allocs;   // tables: freed by mpcb_destroy only
     // hand-over count of the latest solve, copied to page-locked host memory behind the kernels;
     // read (without waiting) at the start of the next solve to size the dense workspace
@@ -284,7 +283,7 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
     }
     {
         int *cnt = nullptr;
-        if (hipMalloc((void **)&cnt, mpcb::COUNTER_INTS * sizeof(int)) != hipSuccess) { // hand-overs to the dense kernel, to the wide edition
+        if (hipMalloc((void **)&cnt, 2 * sizeof(int)) != hipSuccess) { // hand-overs to the dense kernel, to the wide edition
             mpcb_destroy(h);
             return fail(MPCB_E_HIP, "hipMalloc failed");
         }
@@ -325,10 +324,8 @@ namespace {
 // buffers are freed here, after the stream has drained.
 void release_order_buffers(mpcb_handle h) {
     if (h->order) (void)hipFree(h->order);
-    for (int r = 0; r < 2; r++) {
-        if (h->order_rec[r]) (void)hipFree(h->order_rec[r]);
-        h->order_rec[r] = nullptr;
-    }
+    if (h->order_rec) (void)hipFree(h->order_rec);
+    h->order_rec = nullptr;
     h->order = nullptr;
     h->order_capacity = 0;
 }
@@ -367,11 +364,9 @@ int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
         release_order_buffers(h);
         const size_t cap = (size_t)h->list_capacity;
         HIP_TRY(hipMalloc((void **)&h->order, cap * sizeof(int)));
-        for (int r = 0; r < 2; r++) {
-            HIP_TRY(hipMalloc((void **)&h->order_rec[r], (mpcb::ORDER_BINS + cap) * sizeof(int)));
-            // an all-zero histogram is "no record": the first solve runs in index order
-            HIP_TRY(hipMemsetAsync(h->order_rec[r], 0, mpcb::ORDER_BINS * sizeof(int), stream));
-        }
+        HIP_TRY(hipMalloc((void **)&h->order_rec, (mpcb::ORDER_HEADER + cap) * sizeof(int)));
+        // batch size 0 in the header is "no record": the first solve runs in index order
+        HIP_TRY(hipMemsetAsync(h->order_rec, 0, mpcb::ORDER_HEADER * sizeof(int), stream));
         h->order_capacity = (int)cap;
     }
     if (h->dense_in_lds) return 0;
@@ -449,7 +444,7 @@ int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &o
         ds.F3 = h->knot_F3;
         ds.nref = ds.N;
         if (ws.order) HIP_TRY(mpcb::launch_dispatch_order(ws, B, stream));
-        else HIP_TRY(hipMemsetAsync(ws.count, 0, mpcb::COUNTER_INTS * sizeof(int), stream));
+        else HIP_TRY(hipMemsetAsync(ws.count, 0, 2 * sizeof(int), stream));
         if (h->params.solver_mode == MPCB_MODE_DENSE) {
             HIP_TRY(mpcb::launch_list_all(ws, B, stream));
         } else {
@@ -465,13 +460,13 @@ int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &o
         mpcb::DenseWs cold = ws;
         cold.warm_i = nullptr;
         cold.warm_d = nullptr;
-        HIP_TRY(hipMemsetAsync(ws.count, 0, mpcb::COUNTER_INTS * sizeof(int), stream));
+        HIP_TRY(hipMemsetAsync(ws.count, 0, 2 * sizeof(int), stream));
         HIP_TRY(mpcb::launch_list_all(cold, B, stream));
         HIP_TRY(mpcb::launch_dense(h->ds, di, out, cold, dense_grid, stream));
         return 0;
     } else {
         if (ws.order) HIP_TRY(mpcb::launch_dispatch_order(ws, B, stream));
-        else HIP_TRY(hipMemsetAsync(ws.count, 0, mpcb::COUNTER_INTS * sizeof(int), stream));
+        else HIP_TRY(hipMemsetAsync(ws.count, 0, 2 * sizeof(int), stream));
         HIP_TRY(mpcb::launch_zspace(h->ds, di, out, B, ws, stream));
         HIP_TRY(mpcb::launch_zspace_wide(h->ds, di, out, B < WIDE_GRID ? B : WIDE_GRID, ws, stream));
     }
@@ -492,9 +487,7 @@ int solve_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &ou
     mpcb::DenseWs ws = h->ws;
     if (h->dispatch_hint != MPCB_DISPATCH_IN_ORDER && first_stage_runs(h)) {
         ws.order = h->order;
-        ws.order_prev = h->order_rec[h->order_parity ^ 1];
-        ws.order_record = h->order_rec[h->order_parity];
-        h->order_parity ^= 1;
+        ws.order_record = h->order_rec;
     }
     if ((rc = launch_two_stage(h, di, out, B, ws, B < cap ? B : cap, stream))) return rc;
     HIP_TRY(hipMemcpyAsync(h->count_host, h->ws.count, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -655,7 +648,6 @@ int mpcb_solve_coupled_device_noalloc(mpcb_handle h, int32_t B, const mpcb_coupl
     unsigned char *ptr = g_scratch[h->params.device];
     mpcb::DenseWs ws = h->ws;
     ws.order = nullptr; // index order: the order buffers belong to the allocating entry points
-    ws.order_prev = nullptr;
     ws.order_record = nullptr;
     ws.count = reinterpret_cast<int *>(ptr);
     ws.wide_count = ws.count + 1;

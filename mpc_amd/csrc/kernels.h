@@ -68,16 +68,15 @@ constexpr int WARM_F = 32, WARM_FALG = 33, WARM_RNORM = 34;
 
 struct DenseWs {
     int *list;                 // instance indices the first stage could not certify
-    int *count;                // how many; COUNTER_INTS ints: [0] this count, [1] *wide_count, [2..3] the
-                               //   address of order_record (0: none), where the first stage reads it
+    int *count;                // how many
     int *wide_list;            // coupled forms: instances the first edition of the wave-per-QP kernel
     int *wide_count;           //   leaves to its wide edition (working set beyond 32 rows), or NULL
     int *warm_i;               // [B][WARM_STRIDE] hand-over records (see above), or NULL
     double *warm_d;            // [B][WARM_STRIDE]
     int *order;                // dispatch order of the first stage: workgroup w solves instance order[w]
                                //   (a permutation of 0..B-1), or NULL for w itself
-    const int *order_prev;     // [ORDER_BINS + B] record of the previous solve the order is built from
-    int *order_record;         // [ORDER_BINS + B] record this solve leaves (NULL: none)
+    int *order_record;         // [ORDER_HEADER + B] running-time record: the order is built from what the
+                               //   previous solve left in it, then this solve overwrites it (NULL: none)
     double *J, *R;             // workspace: one n x n slot of each per resident workgroup
     const double *J1;          // L1^-T (N x N, column-major, upper triangular)
     const double *zu_col, *xp_col, *xv_col; // Toeplitz first columns of Zu, Xpu, Xvu
@@ -90,10 +89,10 @@ struct DenseWs {
 hipError_t launch_zspace(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int B,
                          const DenseWs &ws, hipStream_t stream);
 
-// Builds ws.order from ws.order_prev (identity unless that record is of a solve of B instances),
-// clears the histogram of ws.order_record and the two counters at ws.count.
+// Builds ws.order from ws.order_record (identity unless that record is of a solve of B instances),
+// stamps the record for the coming solve and clears the two counters at ws.count.
 constexpr int ORDER_BINS = 256;
-constexpr int COUNTER_INTS = 4;
+constexpr int ORDER_HEADER = 4; // ints before the per-instance bins; [0] = batch size of the recorded solve
 hipError_t launch_dispatch_order(const DenseWs &ws, int B, hipStream_t stream);
 
 // Enqueues the wide edition (60-row capacity, a quarter of the occupancy) over ws.wide_list with

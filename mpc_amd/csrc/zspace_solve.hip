@@ -270,17 +270,16 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
 // Kz = Kzp - c Kza with c = height / gravity (three loads per entry instead of one).
 // One QP, solved by the calling wave in its LDS slice `smem` (see the head of the file).
 // Instances this edition cannot finish are appended to wide_list (capacity reached and a wide
-// edition follows) or to unresolved_list (for the dense kernel).  The first edition also notes how
-// long the instance took in the record whose address follows the two counters at
-// unresolved_count, if there is one (see dispatch_order_kernel).
-template <int NPL, bool POLY, bool ROWS, bool HV, bool WIDE>
+// edition follows) or to unresolved_list (for the dense kernel).  RECORD: how long the instance
+// took is noted in order_record (see dispatch_order_kernel).
+template <int NPL, bool POLY, bool ROWS, bool HV, bool WIDE, bool RECORD>
 __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out,
                                                const int inst, const int lane, double *smem, int *unresolved_list,
                                                int *unresolved_count, int *warm_i, double *warm_d, int *wide_list,
-                                               int *wide_count) {
+                                               int *wide_count, int *order_record) {
     constexpr int ES = POLY ? 4 : 2;
     unsigned t_start = 0;
-    if constexpr (!WIDE) t_start = (unsigned)__builtin_amdgcn_s_memtime(); // for the dispatch-order record
+    if constexpr (RECORD) t_start = (unsigned)__builtin_amdgcn_s_memtime();
     typedef typename WaveConfig<POLY, NPL, WIDE>::State WaveState;
     constexpr int QL = WaveState::QL, LDI = WaveState::LDI;
     const int N = sd.N;
@@ -1077,18 +1076,17 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
     if (status == STATUS_UNRESOLVED && lane_e == 0 && unresolved_list)
         unresolved_list[atomicAdd(unresolved_count, 1)] = inst_e; // re-solved by the dense kernel
     if (status == STATUS_TO_WIDE && lane_e == 0) wide_list[atomicAdd(wide_count, 1)] = inst_e;
-    if constexpr (!WIDE) {
-        int *order_record = *reinterpret_cast<int *const *>(unresolved_count + 2);
-        if (order_record && lane_e == 0) {
+    if constexpr (RECORD) {
+        if (lane_e == 0) {
             // bin = running time on a logarithmic scale, 16 bins to the octave (hand-overs count as
-            // the longest); key = bin | rank within the bin << 8
+            // the longest)
             unsigned dt = (unsigned)__builtin_amdgcn_s_memtime() - t_start;
             dt = dt < 16u ? 16u : dt;
             const int oct = 31 - __builtin_clz(dt);
             int bin = (oct - 4) * 16 + (int)((dt >> (oct - 4)) & 15u);
             bin = bin < ORDER_BINS - 2 ? bin : ORDER_BINS - 2;
             if (status == STATUS_UNRESOLVED || status == STATUS_TO_WIDE) bin = ORDER_BINS - 1;
-            order_record[ORDER_BINS + inst_e] = bin | (atomicAdd(order_record + bin, 1) << 8);
+            order_record[ORDER_HEADER + inst_e] = bin;
         }
     }
     if (status == STATUS_UNRESOLVED && warm_i) {
@@ -1283,54 +1281,65 @@ template <int NPL, bool POLY, bool ROWS, bool HV>
 __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
                                                       int *unresolved_list, int *unresolved_count,
                                                       int *warm_i, double *warm_d, int *wide_list,
-                                                      int *wide_count, const int *order) {
+                                                      int *wide_count) {
+    extern __shared__ double smem[];
+    const int inst = ufirst((int)blockIdx.x);
+    if (inst >= B) return;
+    solve_instance<NPL, POLY, ROWS, HV, false, false>(sd, in, out, inst, (int)(threadIdx.x & 63), smem,
+                                                      unresolved_list, unresolved_count, warm_i, warm_d, wide_list,
+                                                      wide_count, nullptr);
+}
+
+// The same with a dispatch order: workgroup w solves instance order[w] and notes its running time
+// in order_record.
+template <int NPL, bool POLY, bool ROWS, bool HV>
+__global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_ordered_kernel(DevSetup sd, DevIn in, mpcb_outputs out,
+                                                      int B, int *unresolved_list, int *unresolved_count,
+                                                      int *warm_i, double *warm_d, int *wide_list,
+                                                      int *wide_count, const int *order, int *order_record) {
     extern __shared__ double smem[];
     if ((int)blockIdx.x >= B) return;
-    const int inst = ufirst(order ? order[blockIdx.x] : (int)blockIdx.x);
-    solve_instance<NPL, POLY, ROWS, HV, false>(sd, in, out, inst, (int)(threadIdx.x & 63), smem, unresolved_list,
-                                               unresolved_count, warm_i, warm_d, wide_list, wide_count);
+    const int inst = ufirst(order[blockIdx.x]);
+    solve_instance<NPL, POLY, ROWS, HV, false, true>(sd, in, out, inst, (int)(threadIdx.x & 63), smem,
+                                                     unresolved_list, unresolved_count, warm_i, warm_d, wide_list,
+                                                     wide_count, order_record);
 }
 
 // Longest first.  The hardware hands workgroups to free wave slots in index order, and a QP
 // takes between half and twice the average time, so with only a few QPs per slot the launch
-// ends with most slots idle while the last-started long ones finish.  When the previous solve of
-// the same batch size left a record -- prev[0..ORDER_BINS) counts per bin of running time,
-// prev[ORDER_BINS + i] = bin | rank << 8 of instance i -- this kernel turns it into the
-// permutation that starts the instances of the highest bin first (a counting sort: position =
-// instances in higher bins + rank).  Without a matching record the order is the identity.  It also
-// clears the histogram the coming solve accumulates into and the two hand-over counters, and leaves
-// the address of the coming solve's record behind them.
-__global__ __launch_bounds__(ORDER_BINS) void dispatch_order_kernel(const int *prev, int *next, int *order,
-                                                                    int *counts, int B) {
-    __shared__ int above[ORDER_BINS];
+// ends with most slots idle while the last-started long ones finish.  When the previous solve
+// through this record was of the same batch size (rec[0] == B), rec[ORDER_HEADER + i] is the
+// running-time bin of its instance i, and this kernel (one workgroup) turns the bins into the
+// permutation that starts the highest bin first: a counting sort, position = instances in higher
+// bins + arrivals before it in its own.  Otherwise the order is the identity.  It also stamps the
+// record with B for the coming solve (which overwrites the bins as its instances finish) and
+// clears the two hand-over counters.
+constexpr int ORDER_THREADS = 1024;
+__global__ __launch_bounds__(ORDER_THREADS) void dispatch_order_kernel(int *rec, int *order, int *counts, int B) {
+    __shared__ int cursor[ORDER_BINS];
     const int t = threadIdx.x;
-    const int mine = prev[t];
-    above[t] = mine;
-    __syncthreads();
-    for (int off = 1; off < ORDER_BINS; off <<= 1) { // inclusive suffix sums
-        const int v = t + off < ORDER_BINS ? above[t + off] : 0;
+    const bool valid = rec[0] == B;
+    if (valid) {
+        if (t < ORDER_BINS) cursor[t] = 0;
         __syncthreads();
-        above[t] += v;
+        for (int i = t; i < B; i += ORDER_THREADS) atomicAdd(&cursor[rec[ORDER_HEADER + i] & (ORDER_BINS - 1)], 1);
         __syncthreads();
+        int above = 0;
+        if (t < ORDER_BINS)
+            for (int b = t + 1; b < ORDER_BINS; b++) above += cursor[b];
+        __syncthreads();
+        if (t < ORDER_BINS) cursor[t] = above;
+        __syncthreads();
+        for (int i = t; i < B; i += ORDER_THREADS)
+            order[atomicAdd(&cursor[rec[ORDER_HEADER + i] & (ORDER_BINS - 1)], 1)] = i;
+    } else {
+        for (int i = t; i < B; i += ORDER_THREADS) order[i] = i;
     }
-    const int total = above[0];
     __syncthreads();
-    above[t] -= mine;
-    __syncthreads();
-    const int i = blockIdx.x * ORDER_BINS + t;
-    if (i < B) {
-        int pos = i;
-        if (total == B) {
-            const int key = prev[ORDER_BINS + i];
-            // (within a bin in reverse order of completion: the later, the longer)
-            pos = above[key & (ORDER_BINS - 1)] + (prev[key & (ORDER_BINS - 1)] - 1 - (key >> 8));
-        }
-        if (pos >= 0 && pos < B) order[pos] = total == B ? i : pos;
-    }
-    if (blockIdx.x == 0) {
-        next[t] = 0;
-        if (t < 2) counts[t] = 0;
-        if (t == 2) *reinterpret_cast<int **>(counts + 2) = next;
+    if (t == 0) {
+        rec[0] = B;
+        counts[0] = 0;
+        counts[1] = 0;
     }
 }
 
@@ -1342,9 +1351,9 @@ __global__ __launch_bounds__(64, 1) void zspace_wide_kernel(DevSetup sd, DevIn i
     extern __shared__ double smem[];
     const int count = ufirst(*work_count);
     for (int entry = blockIdx.x; entry < count; entry += gridDim.x) {
-        solve_instance<NPL, true, ROWS, HV, true>(sd, in, out, ufirst(work_list[entry]), (int)(threadIdx.x & 63), smem,
-                                                  unresolved_list, unresolved_count, nullptr, nullptr, nullptr,
-                                                  nullptr);
+        solve_instance<NPL, true, ROWS, HV, true, false>(sd, in, out, ufirst(work_list[entry]),
+                                                         (int)(threadIdx.x & 63), smem, unresolved_list,
+                                                         unresolved_count, nullptr, nullptr, nullptr, nullptr, nullptr);
         wsync();
     }
 }
@@ -1362,6 +1371,17 @@ hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &o
     // and wave slot are released the moment its QP is done instead of when the slowest of
     // several is (iteration counts differ by 2-3x between instances).
     const size_t shmem = wave_lds_bytes<POLY, NPL, false>(sd);
+    if (ws.order && ws.order_record) {
+        auto kfn = zspace_ordered_kernel<NPL, POLY, ROWS, HV>;
+        if (shmem > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kfn, dim3(B), dim3(64), shmem, stream, sd, in, out, B, ws.list, ws.count, ws.warm_i,
+                           ws.warm_d, POLY ? ws.wide_list : nullptr, ws.wide_count, ws.order, ws.order_record);
+        return hipGetLastError();
+    }
     auto kfn = zspace_kernel<NPL, POLY, ROWS, HV>;
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
@@ -1369,7 +1389,7 @@ hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &o
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kfn, dim3(B), dim3(64), shmem, stream, sd, in, out, B, ws.list, ws.count, ws.warm_i,
-                       ws.warm_d, POLY ? ws.wide_list : nullptr, ws.wide_count, ws.order);
+                       ws.warm_d, POLY ? ws.wide_list : nullptr, ws.wide_count);
     return hipGetLastError();
 }
 
@@ -1424,9 +1444,9 @@ hipError_t launch_zspace(const DevSetup &sd, const DevIn &in, const mpcb_outputs
 }
 
 hipError_t launch_dispatch_order(const DenseWs &ws, int B, hipStream_t stream) {
-    if (B <= 0 || !ws.order || !ws.order_prev || !ws.order_record) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dispatch_order_kernel, dim3((B + ORDER_BINS - 1) / ORDER_BINS), dim3(ORDER_BINS), 0, stream,
-                       ws.order_prev, ws.order_record, ws.order, ws.count, B);
+    if (B <= 0 || !ws.order || !ws.order_record) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dispatch_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, stream, ws.order_record, ws.order,
+                       ws.count, B);
     return hipGetLastError();
 }
 
