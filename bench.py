@@ -315,7 +315,11 @@ def main():
                     help="steps of the host-pointer (PCIe-inclusive) side measurement at N=1; 0 = skip")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="instances timed on the host cores (0 disables, -1 = default)")
+    ap.add_argument("--plain", action="store_true",
+                    help="warm-up and timed steps only (for profiler runs): no side measurements, no CPU baseline")
     args = ap.parse_args()
+    if args.plain:
+        args.host_steps, args.cpu_sample = 0, 0
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -379,7 +383,7 @@ def main():
     # taken from the previous step's running times is as good as it can get -- a caller with
     # unrelated batches gains nothing from the hint, which is why this is not `value`.
     longest_first = None
-    if world == 1:
+    if world == 1 and not args.plain:
         planners = [getattr(wl, a) for a in ("pl", "pl_y") if hasattr(wl, a)]
         for pl in planners:
             pl.set_dispatch_hint(P.DISPATCH_LONGEST_FIRST)
@@ -474,7 +478,7 @@ def main():
             line["longest_first_dispatch"] = longest_first
         if world == 1 and args.host_steps > 0 and hasattr(wl, "host_buffers"):
             line["host_buffers"] = wl.host_buffers(args.host_steps)
-        if hasattr(wl, "feasible_subset"):
+        if hasattr(wl, "feasible_subset") and not args.plain:
             line["feasible_subset"] = wl.feasible_subset()
         prof, prof_file = measured_profile(args.workload)
         r = line["roofline"]

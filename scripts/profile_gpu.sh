@@ -12,7 +12,7 @@ D=$ROOT/gpurun_out/$OUT
 mkdir -p "$D"
 export TMPDIR=/tmp
 cd "$ROOT"
-BENCH="python3 bench.py --workload $WL --steps 5 --warmup 2 --cpu-sample 0 --host-steps 0 $*"
+BENCH="python3 bench.py --workload $WL --steps 5 --warmup 2 --plain $*"
 
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- $BENCH > "$D/trace.log" 2>&1
 echo "trace done"
