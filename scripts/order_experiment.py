@@ -30,7 +30,6 @@ for wl in ("vel", "jerk"):
                           weight_R=0.01, weight_Q=1.0, number_of_steps=20)
     prep = pl.prepare_coupled(**bt)
     report(wl, pl, lambda: pl.solve_coupled_prepared(prep))
-sys.exit(0)
 bt = batches.decoupled_batch(4096)
 pb = P.BatchedPlanner(100, formulation=P.BOX_1D, weight_R=1.0)
 px = pb.prepare_box(bt["x0"], bt["xmin"], bt["xmax"]); py = pb.prepare_box(bt["y0"], bt["ymin"], bt["ymax"])
