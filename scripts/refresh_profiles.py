@@ -46,7 +46,7 @@ def resource_usage(dst):
                            capture_output=True, text=True, cwd=os.path.dirname(src))
         fields = []
         for line in p.stderr.splitlines():
-            m = re.search(r"remark: \S+ (Function Name: .*|\s+\S.*) \[-Rpass-analysis", line)
+            m = re.search(r"remark:\s+(.*?) \[-Rpass-analysis=kernel-resource-usage\]", line)
             if m:
                 fields.append(m.group(1).strip())
         if fields:
