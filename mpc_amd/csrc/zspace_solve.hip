@@ -917,7 +917,7 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
                 STAMP(6);
                 // z != 0 test (:336): ||z||^2 >= zn / lambda_max(G1) >= zn / trace(G1)
                 bool znz;
-                if (zn > 1e-8 * mii && zn > 64.0 * EPS * sd.traceG1) {
+                if (zn > 1e-5 * mii && zn > 64.0 * EPS * sd.traceG1) {
                     znz = true;
                 } else {
                     // explicit z = G^-1 (n_ip - N_A r)
@@ -937,7 +937,7 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
                     znz = fabs(wave_sum(acc)) > EPS;
                     wsync();
                 }
-                if (znz && !(zn > 1e-11 * mii)) {
+                if (znz && !(zn > (POLY ? 1e-7 : 1e-11) * mii)) {
                     // n_ip is numerically dependent on the working set although z is
                     // not negligible: the reduced system has lost its accuracy.
                     status = STATUS_UNRESOLVED;

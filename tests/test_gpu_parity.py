@@ -941,3 +941,63 @@ def test_dispatch_hint_reorders_the_launch_not_the_results(P):
     run(box, prepare_box, lambda prepared, out=None: box.solve_box_prepared(prepared, out=out),
         [(600, 0), (600, 2000), (90, 11)])
     assert box.last_handover_count() > 0
+
+
+def test_nearly_dependent_rows_at_the_solvers_thresholds(P, oracle):
+    """Caller-built rows that put the solver on its z != 0 test (eiquadprog.hpp:336) and on the
+    thresholds of the thin-factor kernel: an active row is moved 5 cm inwards and a second row of
+    the same knot is replaced by its mirror image turned by theta, closing a slab of the given
+    width behind it (negative: the two half-planes only meet far away, or -- theta = 0 -- never).
+
+    theta = 0 and 1e-9: the second normal is exactly / numerically dependent on the first, the
+    reference takes its dual-step-only branch and reports infeasibility after a few iterations.
+    theta = 1e-4: the pair can be added (z . n / n . G^-1 n ~ 3e-9) but leaves a factor with a
+    condition number of ~1e4 that the reference's own arithmetic just survives: the first-stage
+    kernel passes such an instance to the dense kernel.  theta = 1e-2: regular.  Status and
+    iteration count equal the CPU restatement's in all of them, the ordered working set and the
+    jerk too where a solution exists.  (With theta between 1e-7 and 1e-5 and an empty slab the
+    reference itself wanders for ~430 iterations until 399 of the 400 possible rows are active
+    and returns an arbitrary point or 'infeasible' depending on rounding: not compared.)"""
+    N, steps = 200, 20
+    bt = batches.coupled_batch(1, first=13000)
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
+    st = oracle.compute_steps(N, steps, bt["speed"][0], bt["feet_x"][0], bt["feet_y"][0], bt["swing0"][0])
+    A, b = st["A"], st["b"]
+    m = A.shape[0]
+    kn = np.array([np.nonzero(A[r])[0][0] % N for r in range(m)])
+    rows0 = np.array([(A[r, kn[r]], A[r, kn[r] + N], b[r]) for r in range(m)])
+    base = _np(pl.solve_coupled(bt["x0"], bt["y0"], bt["speed"], rows_pqr=rows0[None]))
+    act = base["active_idx"][0, :base["n_active"][0]]
+    ra = int(act[len(act) // 2])
+    k = kn[ra]
+    victim = [r for r in range(m) if kn[r] == k and r != ra][0]
+    p, q, r = rows0[ra]
+    shift = 0.05
+    cases = [(w, th) for w in (-0.05, -0.01) for th in (0.0, 1e-9, 1e-4, 1e-2)]
+    cases += [(w, th) for w in (0.0, 1e-6, 1e-3) for th in (0.0, 1e-9, 1e-7, 1e-5, 1e-4, 1e-2)]
+    allrows = []
+    for width, theta in cases:
+        c, s = np.cos(theta), np.sin(theta)
+        rows = rows0.copy()
+        rows[ra] = (p, q, r - shift)
+        rows[victim] = (-(c * p - s * q), -(s * p + c * q), -(r - shift) + width)
+        allrows.append(rows)
+    allrows = np.array(allrows)
+    rep = lambda a: np.repeat(a, len(cases), axis=0)
+    o = _np(pl.solve_coupled(rep(bt["x0"]), rep(bt["y0"]), rep(bt["speed"]), rows_pqr=allrows))
+    assert pl.last_handover_count() >= 2  # the theta = 1e-4 pairs
+    par = oracle.params(N, R=0.01, Q=1.0, height=0.5, iter_cap=4000)
+    solved = 0
+    for i, (width, theta) in enumerate(cases):
+        A2 = A.copy()
+        A2[victim] = 0.0
+        A2[victim, k], A2[victim, k + N] = allrows[i, victim, 0], allrows[i, victim, 1]
+        ref = oracle.solve_coupled(par, oracle.COUPLED_VEL, bt["x0"][0], bt["y0"][0], A2, allrows[i, :, 2],
+                                   bt["speed"][0], 1000)
+        assert ref["info"].status == o["status"][i], (width, theta)
+        assert ref["info"].iters == o["iters"][i], (width, theta)
+        if ref["info"].status == 0:
+            solved += 1
+            assert list(ref["active"]) == list(o["active_idx"][i, :o["n_active"][i]]), (width, theta)
+            assert _rel(o["jerk_x"][i], ref["jerk_x"]) < RTOL and _rel(o["jerk_y"][i], ref["jerk_y"]) < RTOL
+    assert solved >= 18 and (o["status"][:3] == 1).all()
