@@ -56,6 +56,7 @@ constexpr size_t SCRATCH_BYTES = SCRATCH_R_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BY
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 constexpr int MAX_DEVICES = 64;
 static unsigned char *g_scratch[MAX_DEVICES] = {nullptr};
+static bool g_scratch_clean[MAX_DEVICES] = {false}; // the scratch's counter block is known to be zero
 static std::mutex g_scratch_mutex;
 
 struct mpcb_handle_s {
@@ -68,6 +69,8 @@ struct mpcb_handle_s {
     int slot_target = 16;    // slots wanted: raised to the largest hand-over count seen (<= 512)
     bool dense_in_lds = false; // the dense kernel keeps J and R in LDS: no HBM slots at all
     bool wide_fits = false;    // the wide edition of the first-stage kernel fits the LDS for this shape
+    // the counter block is known to be zero (every completed solve leaves it so): no memset needed
+    bool counters_clean = false;
     // longest-first dispatch of the first stage (mpcb_set_dispatch_hint): the permutation and the
     // running-time record it is built from
     int dispatch_hint = MPCB_DISPATCH_IN_ORDER;
@@ -283,13 +286,13 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
     }
     {
         int *cnt = nullptr;
-        if (hipMalloc((void **)&cnt, 2 * sizeof(int)) != hipSuccess) { // hand-overs to the dense kernel, to the wide edition
+        if (hipMalloc((void **)&cnt, mpcb::COUNTER_INTS * sizeof(int)) != hipSuccess) { // the counter block (kernels.h)
             mpcb_destroy(h);
             return fail(MPCB_E_HIP, "hipMalloc failed");
         }
         h->dev_allocs.push_back(cnt);
         h->ws.count = cnt;
-        h->ws.wide_count = cnt + 1;
+        h->ws.wide_count = cnt + mpcb::CNT_WIDE;
     }
     if (params->formulation != MPCB_UNCONSTRAINED) {
         // the dense kernel's LDS carve-up must fit a workgroup: found out here, not at the
@@ -433,8 +436,22 @@ constexpr int WIDE_GRID = 1024;
 
 // first stage (wave per QP; for the coupled forms its wide edition over the instances whose
 // working set outgrew the first), then the dense kernel over whatever is left
+int enqueue_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &out, int B,
+                      const mpcb::DenseWs &ws, int dense_grid, hipStream_t stream);
+
+// (`clean`: the counter block at ws.count is zero -- the dense kernel of every solve that was
+// enqueued completely leaves it so; otherwise it is cleared here first)
 int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &out, int B,
-                     const mpcb::DenseWs &ws, int dense_grid, hipStream_t stream) {
+                     const mpcb::DenseWs &ws, int dense_grid, hipStream_t stream, bool *clean) {
+    if (!*clean) HIP_TRY(hipMemsetAsync(ws.count, 0, mpcb::COUNTER_INTS * sizeof(int), stream));
+    *clean = false;
+    const int rc = enqueue_two_stage(h, di, out, B, ws, dense_grid, stream);
+    if (rc == 0) *clean = true;
+    return rc;
+}
+
+int enqueue_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &out, int B,
+                      const mpcb::DenseWs &ws, int dense_grid, hipStream_t stream) {
     if (di.zref_knot_mode) {
         // same kernels, the reference's segments are the knots
         mpcb::DevSetup ds = h->ds;
@@ -444,7 +461,6 @@ int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &o
         ds.F3 = h->knot_F3;
         ds.nref = ds.N;
         if (ws.order) HIP_TRY(mpcb::launch_dispatch_order(ws, B, stream));
-        else HIP_TRY(hipMemsetAsync(ws.count, 0, 2 * sizeof(int), stream));
         if (h->params.solver_mode == MPCB_MODE_DENSE) {
             HIP_TRY(mpcb::launch_list_all(ws, B, stream));
         } else {
@@ -460,13 +476,11 @@ int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &o
         mpcb::DenseWs cold = ws;
         cold.warm_i = nullptr;
         cold.warm_d = nullptr;
-        HIP_TRY(hipMemsetAsync(ws.count, 0, 2 * sizeof(int), stream));
         HIP_TRY(mpcb::launch_list_all(cold, B, stream));
         HIP_TRY(mpcb::launch_dense(h->ds, di, out, cold, dense_grid, stream));
         return 0;
     } else {
         if (ws.order) HIP_TRY(mpcb::launch_dispatch_order(ws, B, stream));
-        else HIP_TRY(hipMemsetAsync(ws.count, 0, 2 * sizeof(int), stream));
         HIP_TRY(mpcb::launch_zspace(h->ds, di, out, B, ws, stream));
         HIP_TRY(mpcb::launch_zspace_wide(h->ds, di, out, B < WIDE_GRID ? B : WIDE_GRID, ws, stream));
     }
@@ -489,8 +503,9 @@ int solve_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &ou
         ws.order = h->order;
         ws.order_record = h->order_rec;
     }
-    if ((rc = launch_two_stage(h, di, out, B, ws, B < cap ? B : cap, stream))) return rc;
-    HIP_TRY(hipMemcpyAsync(h->count_host, h->ws.count, sizeof(int), hipMemcpyDeviceToHost, stream));
+    if ((rc = launch_two_stage(h, di, out, B, ws, B < cap ? B : cap, stream, &h->counters_clean))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->count_host, h->ws.count + mpcb::CNT_LAST_HANDOVER, sizeof(int), hipMemcpyDeviceToHost,
+                           stream));
     HIP_TRY(hipEventRecord(h->count_event, stream));
     h->count_pending = true;
     return 0;
@@ -545,7 +560,7 @@ int mpcb_last_wide_count(mpcb_handle h) {
     DeviceGuard guard(h->params.device);
     int n = 0;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&n, h->ws.wide_count, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&n, h->ws.count + mpcb::CNT_LAST_WIDE, sizeof(int), hipMemcpyDeviceToHost));
     return n;
 }
 
@@ -555,7 +570,7 @@ int mpcb_last_handover_count(mpcb_handle h) {
     DeviceGuard guard(h->params.device);
     int n = 0;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&n, h->ws.count, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&n, h->ws.count + mpcb::CNT_LAST_HANDOVER, sizeof(int), hipMemcpyDeviceToHost));
     return n;
 }
 
@@ -650,13 +665,14 @@ int mpcb_solve_coupled_device_noalloc(mpcb_handle h, int32_t B, const mpcb_coupl
     ws.order = nullptr; // index order: the order buffers belong to the allocating entry points
     ws.order_record = nullptr;
     ws.count = reinterpret_cast<int *>(ptr);
-    ws.wide_count = ws.count + 1;
+    ws.wide_count = ws.count + mpcb::CNT_WIDE;
     ws.list = reinterpret_cast<int *>(ptr + SCRATCH_LIST_OFF);
     ws.wide_list = h->wide_fits ? reinterpret_cast<int *>(ptr + SCRATCH_WIDE_OFF) : nullptr;
     ws.J = reinterpret_cast<double *>(ptr + SCRATCH_J_OFF);
     ws.R = reinterpret_cast<double *>(ptr + SCRATCH_R_OFF);
     const int cap = h->dense_in_lds ? 512 : NOALLOC_SLOTS;
-    return launch_two_stage(h, di, *out, B, ws, B < cap ? B : cap, (hipStream_t)stream);
+    return launch_two_stage(h, di, *out, B, ws, B < cap ? B : cap, (hipStream_t)stream,
+                            &g_scratch_clean[h->params.device]);
 }
 
 int mpcb_solve_coupled_multi(const mpcb_handle *handles, int32_t n_handles, int32_t B,

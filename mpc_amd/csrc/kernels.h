@@ -66,9 +66,16 @@ constexpr int WARM_ITERS = 33;    //   warm_d: objective, operation count, R_nor
 constexpr int WARM_PASSES = 34;
 constexpr int WARM_F = 32, WARM_FALG = 33, WARM_RNORM = 34;
 
+// Counter block of a solve (DenseWs::count points at its first entry).  The first stage counts its
+// hand-overs in [CNT_HANDOVER] and [CNT_WIDE]; the dense kernel, always the last launch of a solve,
+// has its last workgroup out copy both to the CNT_LAST_* entries (which the host reads) and zero
+// the block again, so that a solve finds the counters at zero without a memset of its own.
+constexpr int CNT_HANDOVER = 0, CNT_WIDE = 1, CNT_DONE = 2, CNT_LAST_HANDOVER = 3, CNT_LAST_WIDE = 4;
+constexpr int COUNTER_INTS = 8;
+
 struct DenseWs {
     int *list;                 // instance indices the first stage could not certify
-    int *count;                // how many
+    int *count;                // how many: the first of COUNTER_INTS ints, see CNT_* below
     int *wide_list;            // coupled forms: instances the first edition of the wave-per-QP kernel
     int *wide_count;           //   leaves to its wide edition (working set beyond 32 rows), or NULL
     int *warm_i;               // [B][WARM_STRIDE] hand-over records (see above), or NULL
