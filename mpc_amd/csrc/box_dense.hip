@@ -853,7 +853,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) retire_counters(ws.count, gridDim.x);
+    if (threadIdx.x == 0) retire_counters(ws.count, gridDim.x, ws.host_count);
 }
 
 } // namespace

@@ -78,11 +78,10 @@ struct mpcb_handle_s {
     int *order_rec = nullptr;
     int order_capacity = 0;
     std::vector<void *> dev_allocs;   // tables: freed by mpcb_destroy only
-    // hand-over count of the latest solve, copied to page-locked host memory behind the kernels;
-    // read (without waiting) at the start of the next solve to size the dense workspace
+    // hand-over count of the latest finished solve: one int of page-locked host memory that the
+    // dense kernel's last workgroup stores to (DenseWs::host_count); read, without waiting, at the
+    // start of a solve to size the dense workspace
     int *count_host = nullptr;
-    hipEvent_t count_event = nullptr;
-    bool count_pending = false;
     hipStream_t own_stream = nullptr; // stream of the host-pointer entry points
     // COUPLED_REF with a free (per-knot) ZMP reference: Sp, Wp, F2, F3 with one segment per knot
     const double *knot_Sp = nullptr, *knot_Wp = nullptr, *knot_F2 = nullptr, *knot_F3 = nullptr;
@@ -307,13 +306,16 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
                                     " bytes of LDS per workgroup (limit 163840)");
         }
     }
-    if (hipHostMalloc((void **)&h->count_host, sizeof(int), hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&h->count_event, hipEventDisableTiming) != hipSuccess ||
+    if (hipHostMalloc((void **)&h->count_host, sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
         mpcb_destroy(h);
-        return fail(MPCB_E_HIP, "creating the handle's stream, event or pinned counter failed");
+        return fail(MPCB_E_HIP, "creating the handle's stream or pinned counter failed");
     }
     *h->count_host = 0;
+    if (hipHostGetDevicePointer((void **)&h->ws.host_count, h->count_host, 0) != hipSuccess) {
+        mpcb_destroy(h);
+        return fail(MPCB_E_HIP, "hipHostGetDevicePointer failed");
+    }
     *out = h;
     return 0;
 }
@@ -334,12 +336,10 @@ void release_order_buffers(mpcb_handle h) {
 }
 
 int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
-    if (h->count_pending && hipEventQuery(h->count_event) == hipSuccess) {
-        h->count_pending = false;
-        const int seen = *h->count_host;
+    {
+        const int seen = *static_cast<volatile int *>(h->count_host);
         if (seen > h->slot_target) h->slot_target = seen < 512 ? seen : 512;
     }
-    (void)hipGetLastError(); // hipEventQuery reports "not ready" through the error state
     if (B > h->list_capacity) {
         HIP_TRY(hipStreamSynchronize(stream));
         if (h->ws.list) HIP_TRY(hipFree(h->ws.list));
@@ -504,10 +504,6 @@ int solve_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &ou
         ws.order_record = h->order_rec;
     }
     if ((rc = launch_two_stage(h, di, out, B, ws, B < cap ? B : cap, stream, &h->counters_clean))) return rc;
-    HIP_TRY(hipMemcpyAsync(h->count_host, h->ws.count + mpcb::CNT_LAST_HANDOVER, sizeof(int), hipMemcpyDeviceToHost,
-                           stream));
-    HIP_TRY(hipEventRecord(h->count_event, stream));
-    h->count_pending = true;
     return 0;
 }
 
@@ -517,6 +513,8 @@ void mpcb_destroy(mpcb_handle h) {
     if (!h) return;
     {
         DeviceGuard guard(h->params.device);
+        // solves still in flight on the caller's streams read the tables and write the pinned counter
+        (void)hipDeviceSynchronize();
         if (h->own_stream) {
             (void)hipStreamSynchronize(h->own_stream);
             (void)hipStreamDestroy(h->own_stream);
@@ -530,7 +528,6 @@ void mpcb_destroy(mpcb_handle h) {
         if (h->ws.R) (void)hipFree(h->ws.R);
         release_order_buffers(h);
         if (h->stage_dev) (void)hipFree(h->stage_dev);
-        if (h->count_event) (void)hipEventDestroy(h->count_event);
         if (h->count_host) (void)hipHostFree(h->count_host);
     }
     delete h;
@@ -662,6 +659,7 @@ int mpcb_solve_coupled_device_noalloc(mpcb_handle h, int32_t B, const mpcb_coupl
     // the handle's tables with this device's static scratch in place of the allocated workspace
     unsigned char *ptr = g_scratch[h->params.device];
     mpcb::DenseWs ws = h->ws;
+    ws.host_count = nullptr;
     ws.order = nullptr; // index order: the order buffers belong to the allocating entry points
     ws.order_record = nullptr;
     ws.count = reinterpret_cast<int *>(ptr);

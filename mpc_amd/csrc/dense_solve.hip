@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
         }
         __syncthreads();
     }
-    if (tid == 0) retire_counters(ws.count, gridDim.x);
+    if (tid == 0) retire_counters(ws.count, gridDim.x, ws.host_count);
 }
 
 __global__ void list_all_kernel(int *list, int *count, int B) {

@@ -355,9 +355,10 @@ __device__ __forceinline__ double unconstrained_cost_part(const DevSetup &sd, co
 // Called by one thread of every workgroup of the dense kernel after its last instance: the last
 // workgroup out (all others have read the counters by then) keeps the counts of this solve for
 // the host and returns the counter block to zero for the next solve.
-__device__ __forceinline__ void retire_counters(int *counters, unsigned workgroups) {
+__device__ __forceinline__ void retire_counters(int *counters, unsigned workgroups, int *host_count) {
     __threadfence();
     if (atomicAdd(counters + CNT_DONE, 1) == (int)workgroups - 1) {
+        if (host_count) *host_count = counters[CNT_HANDOVER];
         counters[CNT_LAST_HANDOVER] = counters[CNT_HANDOVER];
         counters[CNT_LAST_WIDE] = counters[CNT_WIDE];
         counters[CNT_HANDOVER] = 0;

@@ -76,6 +76,7 @@ constexpr int COUNTER_INTS = 8;
 struct DenseWs {
     int *list;                 // instance indices the first stage could not certify
     int *count;                // how many: the first of COUNTER_INTS ints, see CNT_* below
+    int *host_count;           // page-locked host int that receives the hand-over count of the solve, or NULL
     int *wide_list;            // coupled forms: instances the first edition of the wave-per-QP kernel
     int *wide_count;           //   leaves to its wide edition (working set beyond 32 rows), or NULL
     int *warm_i;               // [B][WARM_STRIDE] hand-over records (see above), or NULL
