@@ -304,6 +304,17 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
     unsigned validm = 0; // bit (c*4+e): the slot exists
 #pragma unroll
     for (int c = 0; c < NPL; c++) kcb[c] = (unsigned)KC(c) * 8u;
+    // phase and first row of the owned knots: asked for here, used after the polygons are built
+    // (from clamped -- always valid -- knots: conditional loads would be issued and waited for one
+    // chunk after the other)
+    int ph_k[NPL], row0_k[NPL];
+    if constexpr (POLY) {
+#pragma unroll
+        for (int c = 0; c < NPL; c++) {
+            ph_k[c] = sd.knot_phase[KC(c)];
+            row0_k[c] = sd.knot_row0[KC(c)];
+        }
+    }
     // Entries of the N x N response tables are fetched by buffer loads: the table is a buffer
     // resource (four scalar registers), the wave-uniform part of the offset (a row, or a column)
     // rides in a scalar register and the lane adds a 32-bit byte offset -- no per-lane 64-bit
@@ -421,13 +432,11 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
                 }
             }
         }
-        // (all loads first, from clamped -- always valid -- knots: conditional loads would be
-        // issued and waited for one chunk after the other)
         int ph[NPL], row0[NPL];
 #pragma unroll
         for (int c = 0; c < NPL; c++) {
-            ph[c] = sd.knot_phase[KC(c)];
-            row0[c] = sd.knot_row0[KC(c)];
+            ph[c] = ph_k[c];
+            row0[c] = row0_k[c];
         }
 #pragma unroll
         for (int c = 0; c < NPL; c++) {
