@@ -28,3 +28,10 @@ print("%s, %d instances: status differs on %d, iteration count on %d, ordered wo
       "trajectory error %.2e; handed over %d" %
       (form, B, int((o["status"] != ref["status"]).sum()), int((o["iters"] != ref["iters"]).sum()), len(bad_ws), worst,
        pl.last_handover_count()))
+# the same batch with the longest-first dispatch order (built from the solve above, then from itself)
+pl.set_dispatch_hint(P.DISPATCH_LONGEST_FIRST)
+same = True
+for _ in range(3):
+    o2 = {k: v.cpu().numpy() for k, v in pl.solve_coupled(**bt).items()}
+    same = same and all(np.array_equal(o[k], o2[k], equal_nan=True) for k in o)
+print("   with mpcb_set_dispatch_hint(LONGEST_FIRST), three solves: every output bit-identical to the index-order solve: %s" % same)
