@@ -1001,3 +1001,40 @@ def test_nearly_dependent_rows_at_the_solvers_thresholds(P, oracle):
             assert list(ref["active"]) == list(o["active_idx"][i, :o["n_active"][i]]), (width, theta)
             assert _rel(o["jerk_x"][i], ref["jerk_x"]) < RTOL and _rel(o["jerk_y"][i], ref["jerk_y"]) < RTOL
     assert solved >= 18 and (o["status"][:3] == 1).all()
+
+
+def test_dispatch_hint_in_the_replanning_sweep_and_the_host_entry_point(P):
+    """With LONGEST_FIRST every stage of a sweep is ordered by the stage before it, and the
+    host-pointer entry point by the handle's previous solve: per-stage records, final plans and
+    evolved states are those of the index-order sweep, bit for bit."""
+    import torch
+    B, N, steps, stages = 300, 200, 20, 4
+    inputs = batches.coupled_batch(B, first=7000)
+    dist = batches.replanning_disturbance(B, first=7000)
+
+    def sweep(hint):
+        pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0,
+                              replanning_window=N // steps, number_of_steps=steps,
+                              hip_offsets=batches.NOMINAL_HIP_OFFSETS)
+        pl.set_dispatch_hint(hint)
+        prepared = pl.prepare_replanning(disturbance=dist, **inputs)
+        res, stage, state = pl.replan_sweep(prepared, stages)
+        torch.cuda.synchronize()
+        out = {k: v.cpu().numpy() for k, v in res.items()}
+        out.update({"stage_" + k: v.cpu().numpy() for k, v in stage.items()})
+        out.update({"state_" + k: state[k].cpu().numpy() for k in ("x0", "y0", "feet_x", "feet_y", "swing0")})
+        return out
+
+    plain, ordered = sweep(P.DISPATCH_IN_ORDER), sweep(P.DISPATCH_LONGEST_FIRST)
+    assert set(plain) == set(ordered)
+    for k, v in plain.items():
+        assert np.array_equal(ordered[k], v, equal_nan=True), k
+
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_JERK, weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
+    args = [inputs[k] for k in ("x0", "y0", "speed", "feet_x", "feet_y", "swing0")]
+    ref = {k: np.array(v) for k, v in pl.solve_coupled_host(*args).items()}
+    pl.set_dispatch_hint(P.DISPATCH_LONGEST_FIRST)
+    for _ in range(2):
+        got = pl.solve_coupled_host(*args)
+        for k, v in ref.items():
+            assert np.array_equal(np.array(got[k]), v, equal_nan=True), k
