@@ -7,4 +7,5 @@ cb = d.get('cpu_baseline') or {}
 print(w, '%.4g' % d['value'], d['unit'], 'ms/step', round(d['ms_per_step'], 4), 'frac', d['roofline'].get('frac'),
       'kernel_ms', round(d['roofline'].get('kernel_ms'), 4), 'cpu', round(cb.get('value', 0)),
       'ratio', round(d.get('speedup_vs_cpu_baseline', 0)), 'structured', round((d.get('cpu_structured') or {}).get('value', 0)),
-      'longest-first', '%.4g' % lf.get('value', 0), round(lf.get('ms_per_step', 0), 4))
+      'longest-first', '%.4g' % lf.get('value', 0), round(lf.get('ms_per_step', 0), 4),
+      'second pass', '%.4g' % (d.get('second_pass') or {}).get('value', 0))
