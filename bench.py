@@ -21,6 +21,10 @@ Workloads (--workload):
 
 Instances are independent, so rank r solves instances [r*B, (r+1)*B) of one global batch
 and nothing is exchanged during a step (weak scaling).
+
+Before the W warm-up steps the step is repeated, untimed, for --settle-ms (default 60 ms; the
+line reports it): a step of the default workload lasts 0.24 ms, and a GPU that has been idle runs
+its first 10-20 ms of work ~5 % below the speed it then keeps.  --settle-ms 0 switches it off.
 """
 import argparse
 import json
@@ -315,11 +319,13 @@ def main():
                     help="steps of the host-pointer (PCIe-inclusive) side measurement at N=1; 0 = skip")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="instances timed on the host cores (0 disables, -1 = default)")
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="untimed repetition of the step before the warm-up, for this long (0 = none)")
     ap.add_argument("--plain", action="store_true",
                     help="warm-up and timed steps only (for profiler runs): no side measurements, no CPU baseline")
     args = ap.parse_args()
     if args.plain:
-        args.host_steps, args.cpu_sample = 0, 0
+        args.host_steps, args.cpu_sample, args.settle_ms = 0, 0, 0.0
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -355,8 +361,19 @@ def main():
         if distributed:
             dist.barrier()
 
+    # Device settling, before the W warm-up steps and reported in the line: a step of the headline
+    # workload takes 0.24 ms, so W = 5 of them leave a GPU that was idle until now 1.2 ms to
+    # raise its clocks, and the first 10-20 ms of work run ~5 % slower than everything after.
+    # The same steps are repeated for a fixed time first; nothing of it is timed or counted.
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        wl.step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         wl.step()
+    # (the first timing event of a process is expensive to record: not inside the timed region)
+    ev_init = torch.cuda.Event(enable_timing=True)
+    ev_init.record()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -366,6 +383,7 @@ def main():
     ev0.record()
     for _ in range(args.steps):
         wl.step()
+    t_issued = time.perf_counter()
     ev1.record()
     torch.cuda.synchronize()
     t1 = time.perf_counter()  # this rank's K steps are done; the MAX over ranks below is the job's time
@@ -448,6 +466,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": wl.describe(),
+            # rank 0's clocks of the timed region: wall, the device's span between the two events
+            # around the K steps, and when the host had issued the last launch
+            "settle_ms": args.settle_ms,
+            "timing": {"wall_ms": (t1 - t0) * 1e3, "device_span_ms": ev0.elapsed_time(ev1),
+                       "all_launches_issued_ms": (t_issued - t0) * 1e3},
             "roofline": {
                 "bound": "fp64_vector",
                 # filled in below from the counter profile of THIS source (fp64 operations the
