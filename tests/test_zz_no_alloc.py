@@ -57,6 +57,11 @@ def test_no_alloc_entry_point_matches_allocating_one(P):
     _compare(P, easy, 96, 0, False)
     _compare(P, easy, 33, 96, False)
     _compare(P, hard, 20, 900, False, True)  # and the first handle again, after others used the scratch
+    # a handle set to longest-first dispatch: the allocating path orders its launch (second call on:
+    # from the record of the one before), the no-alloc path always runs in index order -- same results
+    easy.set_dispatch_hint(P.DISPATCH_LONGEST_FIRST)
+    _compare(P, easy, 96, 200, False)
+    _compare(P, easy, 96, 300, False)
 
 
 def test_no_alloc_entry_point_rejects_sizes_beyond_its_scratch(P):
