@@ -176,6 +176,8 @@ class ReplanningWorkload:
         self.stage = None
 
     def step(self):
+        # (ordering a stage by the one a gait cycle -- four stages -- before it pays from about
+        # sixteen stages on: 52.9 -> 51.3 ms for 24; with eight it only costs the ordering kernels)
         for k, t in self.pristine.items():  # every sweep starts from the same initial state
             self.prepared[2][k].copy_(t)
         _, self.stage, _ = self.pl.replan_sweep(self.prepared, self.STAGES, out=self.out)
@@ -402,10 +404,14 @@ def main():
     # unrelated batches gains nothing from the hint, which is why this is not `value`.
     longest_first = None
     second_pass = None
+    base_hint = getattr(wl, "dispatch_hint", P.DISPATCH_IN_ORDER)
     if world == 1 and not args.plain:
         planners = [getattr(wl, a) for a in ("pl", "pl_y") if hasattr(wl, a)]
+        # (a workload may set `dispatch_hint` as part of its configuration: the comparison is then
+        # with index order)
+        other = P.DISPATCH_LONGEST_FIRST if base_hint == P.DISPATCH_IN_ORDER else P.DISPATCH_IN_ORDER
         for pl in planners:
-            pl.set_dispatch_hint(P.DISPATCH_LONGEST_FIRST)
+            pl.set_dispatch_hint(other)
         for _ in range(max(3, args.warmup)):
             wl.step()
         torch.cuda.synchronize()
@@ -415,9 +421,18 @@ def main():
         torch.cuda.synchronize()
         dt_h = (time.perf_counter() - t_h) / args.steps
         for pl in planners:
-            pl.set_dispatch_hint(P.DISPATCH_IN_ORDER)
-        wl.step()  # the results reported below are those of an index-order solve
+            pl.set_dispatch_hint(base_hint)
+        for _ in range(2):
+            wl.step()  # the results reported below are those of the timed configuration
         torch.cuda.synchronize()
+        if other == P.DISPATCH_LONGEST_FIRST:
+            note = ("same steps with mpcb_set_dispatch_hint(LONGEST_FIRST): the first-stage kernel starts the "
+                    "instances in decreasing order of the running times the previous step recorded for the "
+                    "identical batch (scheduling only, results identical)")
+        else:
+            note = "same steps with every stage dispatched in index order (mpcb_set_dispatch_hint(0))"
+        longest_first = {"value": wl.units / dt_h, "unit": wl.unit, "ms_per_step": dt_h * 1e3, "dispatch_hint": other,
+                         "note": note}
         # ... and the timed steps once more, now that the GPU has been busy for a while: on a
         # GPU that was idle until the warm-up the first milliseconds of work run a few percent
         # slower than the steady state
@@ -427,11 +442,7 @@ def main():
         torch.cuda.synchronize()
         dt_r = (time.perf_counter() - t_r) / args.steps
         second_pass = {"value": wl.units / dt_r, "unit": wl.unit, "ms_per_step": dt_r * 1e3,
-                       "note": "the same K index-order steps timed again at the end of the run"}
-        longest_first = {"value": wl.units / dt_h, "unit": wl.unit, "ms_per_step": dt_h * 1e3,
-                         "note": "same steps with mpcb_set_dispatch_hint(LONGEST_FIRST): the first-stage kernel "
-                                 "starts the instances in decreasing order of the running times the previous step "
-                                 "recorded for the identical batch (scheduling only, results identical)"}
+                       "note": "the same K steps timed again at the end of the run"}
 
     res = wl.results()
     epilogue = None
@@ -509,7 +520,7 @@ def main():
         if epilogue is not None:
             line["epilogue_best_cost"] = epilogue
         if longest_first is not None:
-            line["longest_first_dispatch"] = longest_first
+            line["longest_first_dispatch" if longest_first["dispatch_hint"] else "index_order_dispatch"] = longest_first
         if second_pass is not None:
             line["second_pass"] = second_pass
         if world == 1 and args.host_steps > 0 and hasattr(wl, "host_buffers"):

@@ -252,18 +252,21 @@ int  mpcb_last_wide_count(mpcb_handle h);
 
 /* Scheduling only, no counterpart in the reference (which solves one QP at a time): the order in
  * which the first-stage kernel starts the instances of a batch.  Results do not depend on it.
- * MPCB_DISPATCH_IN_ORDER (default): by instance index.  MPCB_DISPATCH_LONGEST_FIRST: every solve
- * records the running time of each instance, and the next solve of the same batch size on
- * this handle starts the instances that took longest first (index order when there is no such
- * record).  A QP's running time spans a factor of two to three within a batch, so with a few
+ * mode 0 = MPCB_DISPATCH_IN_ORDER (default): by instance index.  mode k = 1 .. MPCB_DISPATCH_MAX_LAG:
+ * every solve records the running time of each instance, and a solve of the same batch size starts
+ * the instances that took longest in the k-th solve before it first (index order while there is no
+ * such record).  A QP's running time spans a factor of two to three within a batch, so with a few
  * instances per wave slot the launch otherwise ends waiting for long instances that started
- * late; callers that solve a slowly changing batch again and again (a receding-horizon loop)
- * gain 10-25 %, unrelated batches gain nothing and lose nothing.  Costs 2 B ints of
- * device memory, allocated by the next solve.  In mpcb_replan_sweep_device every stage is ordered
- * by the stage before it (of no use when a stage advances a whole footstep: the running times
- * of consecutive stages are then unrelated).  The _noalloc entry point always runs in index
- * order. */
-enum { MPCB_DISPATCH_IN_ORDER = 0, MPCB_DISPATCH_LONGEST_FIRST = 1 };
+ * late.  k = 1 (MPCB_DISPATCH_LONGEST_FIRST) is for callers that solve a slowly changing batch
+ * again and again: 10-25 % at 8,192 instances; k = the number of legs in the gait cycle (4 for
+ * the crawl) is for a loop that re-plans every rollout once per footstep, as
+ * testPlannerXYconstraintMPC.cpp does -- consecutive replans then have unrelated running times
+ * (another leg swings first), those a gait cycle apart correlate at 0.8-0.97.  Unrelated batches
+ * gain nothing and lose nothing.  Costs (MPCB_DISPATCH_MAX_LAG + 1) B ints of device memory,
+ * allocated by the next solve.  mpcb_replan_sweep_device uses the records of its own stages only
+ * (stage s is ordered by stage s - k of the same call).  The _noalloc entry point always runs in
+ * index order. */
+enum { MPCB_DISPATCH_IN_ORDER = 0, MPCB_DISPATCH_LONGEST_FIRST = 1, MPCB_DISPATCH_MAX_LAG = 8 };
 int  mpcb_set_dispatch_hint(mpcb_handle h, int32_t mode);
 
 /* Diagnostic builds only (library compiled with -DMPCB_STAMPS): device buffer of 16 cycle

@@ -72,11 +72,13 @@ struct mpcb_handle_s {
     // the counter block is known to be zero (every completed solve leaves it so): no memset needed
     bool counters_clean = false;
     // longest-first dispatch of the first stage (mpcb_set_dispatch_hint): the permutation and the
-    // running-time record it is built from
+    // running-time records it is built from -- a ring of dispatch_hint records, so that a solve is
+    // ordered by the record of the solve that many calls before it, which it then overwrites
     int dispatch_hint = MPCB_DISPATCH_IN_ORDER;
     int *order = nullptr;
-    int *order_rec = nullptr;
+    int *order_rec = nullptr;   // MPCB_DISPATCH_MAX_LAG records of ORDER_HEADER + order_capacity ints
     int order_capacity = 0;
+    unsigned order_calls = 0;   // ordered solves so far: the ring position
     std::vector<void *> dev_allocs;   // tables: freed by mpcb_destroy only
     // hand-over count of the latest finished solve: one int of page-locked host memory that the
     // dense kernel's last workgroup stores to (DenseWs::host_count); read, without waiting, at the
@@ -335,6 +337,16 @@ void release_order_buffers(mpcb_handle h) {
     h->order_capacity = 0;
 }
 
+hipError_t forget_order_records(mpcb_handle h, hipStream_t stream) {
+    if (!h->order_rec) return hipSuccess;
+    const size_t rec = mpcb::ORDER_HEADER + (size_t)h->order_capacity;
+    for (int r = 0; r < MPCB_DISPATCH_MAX_LAG; r++) {
+        hipError_t e = hipMemsetAsync(h->order_rec + r * rec, 0, mpcb::ORDER_HEADER * sizeof(int), stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
     {
         const int seen = *static_cast<volatile int *>(h->count_host);
@@ -367,10 +379,11 @@ int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
         release_order_buffers(h);
         const size_t cap = (size_t)h->list_capacity;
         HIP_TRY(hipMalloc((void **)&h->order, cap * sizeof(int)));
-        HIP_TRY(hipMalloc((void **)&h->order_rec, (mpcb::ORDER_HEADER + cap) * sizeof(int)));
-        // batch size 0 in the header is "no record": the first solve runs in index order
-        HIP_TRY(hipMemsetAsync(h->order_rec, 0, mpcb::ORDER_HEADER * sizeof(int), stream));
+        const size_t rec = mpcb::ORDER_HEADER + cap;
+        HIP_TRY(hipMalloc((void **)&h->order_rec, MPCB_DISPATCH_MAX_LAG * rec * sizeof(int)));
         h->order_capacity = (int)cap;
+        // batch size 0 in a header is "no record": solves run in index order until there is one
+        HIP_TRY(forget_order_records(h, stream));
     }
     if (h->dense_in_lds) return 0;
     int want = h->params.solver_mode == MPCB_MODE_DENSE ? 512 : h->slot_target;
@@ -501,7 +514,8 @@ int solve_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &ou
     mpcb::DenseWs ws = h->ws;
     if (h->dispatch_hint != MPCB_DISPATCH_IN_ORDER && first_stage_runs(h)) {
         ws.order = h->order;
-        ws.order_record = h->order_rec;
+        ws.order_record = h->order_rec + (size_t)(h->order_calls++ % (unsigned)h->dispatch_hint) *
+                                             (mpcb::ORDER_HEADER + (size_t)h->order_capacity);
     }
     if ((rc = launch_two_stage(h, di, out, B, ws, B < cap ? B : cap, stream, &h->counters_clean))) return rc;
     return 0;
@@ -545,8 +559,16 @@ int mpcb_debug_set_stamp_buffer(mpcb_handle h, long long *dev) {
 
 int mpcb_set_dispatch_hint(mpcb_handle h, int32_t mode) {
     if (!h) return fail(MPCB_E_ARG, "null handle");
-    if (mode != MPCB_DISPATCH_IN_ORDER && mode != MPCB_DISPATCH_LONGEST_FIRST)
-        return fail(MPCB_E_ARG, "unknown dispatch hint");
+    if (mode < MPCB_DISPATCH_IN_ORDER || mode > MPCB_DISPATCH_MAX_LAG)
+        return fail(MPCB_E_ARG, "dispatch hint out of range (0 .. MPCB_DISPATCH_MAX_LAG)");
+    if (mode != h->dispatch_hint && h->order_rec) {
+        // another lag: the ring's records no longer sit where the new stride looks for them
+        DeviceGuard guard(h->params.device);
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(forget_order_records(h, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        h->order_calls = 0;
+    }
     h->dispatch_hint = mode;
     return 0;
 }
@@ -774,6 +796,11 @@ int mpcb_replan_sweep_device(mpcb_handle h, int32_t B, int32_t n_stages, int32_t
     sp.stage_cost = stage_cost;
     sp.stage_status = stage_status;
     sp.stage_nactive = stage_nactive;
+    // a sweep is ordered by its own stages only: records of earlier calls are dropped
+    if (h->dispatch_hint != MPCB_DISPATCH_IN_ORDER) {
+        HIP_TRY(forget_order_records(h, s));
+        h->order_calls = 0;
+    }
     for (int stage = 0; stage < n_stages; stage++) {
         int rc = solve_two_stage(h, di, *out, B, s);
         if (rc) return rc;

@@ -198,9 +198,9 @@ class BatchedPlanner:
         return C.c_void_p(stream.cuda_stream)
 
     def set_dispatch_hint(self, mode):
-        """DISPATCH_IN_ORDER (default) or DISPATCH_LONGEST_FIRST: start the instances of the next
-        solves in decreasing order of the iteration counts the solve before recorded (scheduling
-        only: results do not change)."""
+        """0 = DISPATCH_IN_ORDER (default); k = 1 (DISPATCH_LONGEST_FIRST) .. 8: start the instances
+        of a solve in decreasing order of the running times the k-th solve before it recorded
+        (scheduling only: results do not change)."""
         _check(load_library().mpcb_set_dispatch_hint(self._h, int(mode)))
 
     def last_wide_count(self):

@@ -28,4 +28,7 @@ for s in range(8):
     if s:
         line += "  corr with previous stage %.3f  LPT(previous) %.3f" % (
             np.corrcoef(its[s - 1], c)[0, 1], makespan(c[np.argsort(-its[s - 1])]) / (c.sum() / 2048))
+    for lag in (2, 3, 4):
+        if s >= lag:
+            line += "  corr lag %d: %.3f" % (lag, np.corrcoef(its[s - lag], c)[0, 1])
     print(line)

@@ -1004,9 +1004,9 @@ def test_nearly_dependent_rows_at_the_solvers_thresholds(P, oracle):
 
 
 def test_dispatch_hint_in_the_replanning_sweep_and_the_host_entry_point(P):
-    """With LONGEST_FIRST every stage of a sweep is ordered by the stage before it, and the
-    host-pointer entry point by the handle's previous solve: per-stage records, final plans and
-    evolved states are those of the index-order sweep, bit for bit."""
+    """With a dispatch hint k every stage of a sweep is ordered by the k-th stage before it, and the
+    host-pointer entry point by the handle's k-th previous solve: per-stage records, final plans
+    and evolved states are those of the index-order sweep, bit for bit."""
     import torch
     B, N, steps, stages = 300, 200, 20, 4
     inputs = batches.coupled_batch(B, first=7000)
@@ -1025,16 +1025,22 @@ def test_dispatch_hint_in_the_replanning_sweep_and_the_host_entry_point(P):
         out.update({"state_" + k: state[k].cpu().numpy() for k in ("x0", "y0", "feet_x", "feet_y", "swing0")})
         return out
 
-    plain, ordered = sweep(P.DISPATCH_IN_ORDER), sweep(P.DISPATCH_LONGEST_FIRST)
-    assert set(plain) == set(ordered)
-    for k, v in plain.items():
-        assert np.array_equal(ordered[k], v, equal_nan=True), k
+    plain = sweep(P.DISPATCH_IN_ORDER)
+    # lag 1: by the stage before; lag 3: a ring of three records, stage s ordered by stage s - 3
+    for hint in (P.DISPATCH_LONGEST_FIRST, 3):
+        ordered = sweep(hint)
+        assert set(plain) == set(ordered)
+        for k, v in plain.items():
+            assert np.array_equal(ordered[k], v, equal_nan=True), (hint, k)
 
     pl = P.BatchedPlanner(N, formulation=P.COUPLED_JERK, weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
     args = [inputs[k] for k in ("x0", "y0", "speed", "feet_x", "feet_y", "swing0")]
     ref = {k: np.array(v) for k, v in pl.solve_coupled_host(*args).items()}
-    pl.set_dispatch_hint(P.DISPATCH_LONGEST_FIRST)
-    for _ in range(2):
-        got = pl.solve_coupled_host(*args)
-        for k, v in ref.items():
-            assert np.array_equal(np.array(got[k]), v, equal_nan=True), k
+    for hint in (P.DISPATCH_LONGEST_FIRST, 2, 8, P.DISPATCH_LONGEST_FIRST):  # changing the lag drops the records
+        pl.set_dispatch_hint(hint)
+        for _ in range(3):
+            got = pl.solve_coupled_host(*args)
+            for k, v in ref.items():
+                assert np.array_equal(np.array(got[k]), v, equal_nan=True), (hint, k)
+    with pytest.raises(P.MpcError, match="out of range"):
+        pl.set_dispatch_hint(9)
