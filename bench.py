@@ -371,6 +371,10 @@ def main():
     # workload takes 0.24 ms, so W = 5 of them leave a GPU that was idle until now 1.2 ms to
     # raise its clocks, and the first 10-20 ms of work run ~5 % slower than everything after.
     # The same steps are repeated for a fixed time first; nothing of it is timed or counted.
+    # (The first collective of a process group sets up its communicator, which takes far longer
+    # than a step and leaves the GPU idle meanwhile: it happens here, so that the barrier in front
+    # of the timed region is a short one.)
+    barrier()
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
         wl.step()
