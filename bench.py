@@ -228,36 +228,72 @@ class DecoupledWorkload:
         self.name = "decoupled"
         self.inputs = batches.decoupled_batch(B, N=self.N, steps=10, first=first)
         # one handle per axis: a handle is bound to one stream at a time, and the two axes of a
-        # pair are independent QPs, so they run on two streams (the Y axis fills the CUs that the
+        # pair are independent QPs, so they run on separate streams (the Y axis fills the CUs that the
         # X axis' second-stage kernel, one workgroup per CU, leaves idle)
         self.pl = P.BatchedPlanner(self.N, formulation=P.BOX_1D, weight_R=1.0, device=dev)
         self.pl_y = P.BatchedPlanner(self.N, formulation=P.BOX_1D, weight_R=1.0, device=dev)
-        # the X axis carries the long second stage, so it gets the high-priority stream: its first
-        # stage is dispatched ahead of the Y axis' instead of sharing the CUs with it
-        self.hi = torch.cuda.Stream(device=dev, priority=-1)
+        # The X axis carries the long second stage -- a step lasts as long as its first stage plus
+        # its longest instance of the second -- so it gets high-priority streams, and it is solved as
+        # X_PARTS sub-batches with a handle and a stream each: the second stage of a sub-batch starts
+        # when that sub-batch's first stage is done, not the whole axis'.
+        self.parts = self.X_PARTS if B % self.X_PARTS == 0 and B >= 1024 else 1
+        self.pl_more = [P.BatchedPlanner(self.N, formulation=P.BOX_1D, weight_R=1.0, device=dev)
+                        for _ in range(self.parts - 1)]
+        self.hi = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(self.parts)]
         self.side = torch.cuda.Stream(device=dev, priority=0)
+        # The first sub-batch's stream is also the stream the benchmark runs on (main() makes it
+        # the current one): a step forks from it and joins back into it.  With the default stream
+        # as a fourth party of these waits, back-to-back steps stopped making progress on a GPU box
+        # with four hardware queues per process.
+        self.main_stream = self.hi[0]
         self.ev_fork = torch.cuda.Event()
         self.ev_join = torch.cuda.Event()
-        self.ev_join_x = torch.cuda.Event()
+        self.ev_join_x = [torch.cuda.Event() for _ in range(self.parts)]
         i = self.inputs
-        self.px = self.pl.prepare_box(i["x0"], i["xmin"], i["xmax"])
+        self.px = None
         self.py = self.pl_y.prepare_box(i["y0"], i["ymin"], i["ymax"])
         self.outx = self.pl._alloc_outputs(B, P.ALL_OUTPUTS)
         self.outy = self.pl._alloc_outputs(B, P.ALL_OUTPUTS)
+        self._prepare_x()
         self.units = B  # one unit = one X/Y pair (two scalar QPs)
-        self.launches = 2
+        self.launches = self.parts + 1  # second-stage launches per step: the X sub-batches' and the Y axis'
         self.alg_bytes = 2 * B * (8 * (3 + 2 * self.N + 2 * self.N + 1) + 4 * (self.pl.active_stride + 4))
+
+    X_PARTS = 2
+
+    def _x_planners(self):
+        return [self.pl] + self.pl_more
+
+    def _prepare_x(self):
+        """Inputs and output views of the X axis' sub-batches (views into self.outx: the results of the
+        axis stay one set of [B, ...] arrays)."""
+        i = self.inputs
+        n = i["x0"].shape[0]
+        per = n // self.parts
+        self.px, self.outx_part = [], []
+        for p, pl in enumerate(self._x_planners()):
+            sl = slice(p * per, (p + 1) * per)
+            self.px.append(pl.prepare_box(i["x0"][sl], i["xmin"][sl], i["xmax"][sl]))
+            self.outx_part.append(pl.output_views(self.outx, p * per, per))
 
     def step(self):
         main = torch.cuda.current_stream()
         self.ev_fork.record(main)
-        self.hi.wait_event(self.ev_fork)
+        joins = []
+        for p, pl in enumerate(self._x_planners()):
+            st = self.hi[p]
+            own = st.cuda_stream != main.cuda_stream
+            if own:
+                st.wait_event(self.ev_fork)
+            pl.solve_box_prepared(self.px[p], out=self.outx_part[p], stream=st)
+            if own:
+                self.ev_join_x[p].record(st)
+                joins.append(self.ev_join_x[p])
         self.side.wait_event(self.ev_fork)
-        self.pl.solve_box_prepared(self.px, out=self.outx, stream=self.hi)
         self.pl_y.solve_box_prepared(self.py, out=self.outy, stream=self.side)
-        self.ev_join_x.record(self.hi)
         self.ev_join.record(self.side)
-        main.wait_event(self.ev_join_x)
+        for e in joins:
+            main.wait_event(e)
         main.wait_event(self.ev_join)
 
     def results(self):
@@ -268,12 +304,14 @@ class DecoupledWorkload:
 
     def describe(self):
         return {"workload": self.name, "xy_pairs_per_gpu": self.B, "horizon": self.N,
-                "variables": 100, "constraints": 200, "weights": {"R": 1.0}, "seed": batches.SEED}
+                "variables": 100, "constraints": 200, "weights": {"R": 1.0}, "seed": batches.SEED,
+                "x_axis_sub_batches": self.parts}
 
     def second_stage_instances(self):
         self.step()
         torch.cuda.synchronize()
-        return {"x_axis": self.pl.last_handover_count(), "y_axis": self.pl_y.last_handover_count()}
+        return {"x_axis": sum(pl.last_handover_count() for pl in self._x_planners()),
+                "y_axis": self.pl_y.last_handover_count()}
 
     def feasible_subset(self, steps=10):
         """Throughput over the pairs whose two QPs are feasible (the infeasible X-axis draws, kept in
@@ -283,11 +321,12 @@ class DecoupledWorkload:
         n = int(ok.sum())
         if n == 0:
             return None
-        keep = (self.px, self.py, self.outx, self.outy)
-        self.px = self.pl.prepare_box(i["x0"], i["xmin"], i["xmax"])
+        keep = (self.px, self.py, self.outx, self.outy, self.outx_part, self.inputs, self.parts, self.pl_more)
+        self.inputs, self.parts, self.pl_more = i, 1, []  # (an odd number of pairs: one X sub-batch)
         self.py = self.pl_y.prepare_box(i["y0"], i["ymin"], i["ymax"])
         self.outx = self.pl._alloc_outputs(n, P.ALL_OUTPUTS)
         self.outy = self.pl._alloc_outputs(n, P.ALL_OUTPUTS)
+        self._prepare_x()
         for _ in range(2):
             self.step()
         torch.cuda.synchronize()
@@ -296,7 +335,7 @@ class DecoupledWorkload:
             self.step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / steps
-        self.px, self.py, self.outx, self.outy = keep
+        self.px, self.py, self.outx, self.outy, self.outx_part, self.inputs, self.parts, self.pl_more = keep
         return {"pairs": n, "value": n / dt, "unit": "solves/s", "ms_per_step": dt * 1e3}
 
     def cpu_baseline(self, threads, sample):
@@ -363,6 +402,9 @@ def main():
                 "coupled_ref": P.COUPLED_REF}[args.workload]
         wl = CoupledWorkload(form, B, rank * B, dev)
 
+    if hasattr(wl, "main_stream"):
+        torch.cuda.set_stream(wl.main_stream)  # the workload forks from and joins into this stream
+
     def barrier():
         if distributed:
             dist.barrier()
@@ -414,7 +456,7 @@ def main():
     second_pass = None
     base_hint = getattr(wl, "dispatch_hint", P.DISPATCH_IN_ORDER)
     if world == 1 and not args.plain:
-        planners = [getattr(wl, a) for a in ("pl", "pl_y") if hasattr(wl, a)]
+        planners = [getattr(wl, a) for a in ("pl", "pl_y") if hasattr(wl, a)] + list(getattr(wl, "pl_more", []))
         # (a workload may set `dispatch_hint` as part of its configuration: the comparison is then
         # with index order)
         other = P.DISPATCH_LONGEST_FIRST if base_hint == P.DISPATCH_IN_ORDER else P.DISPATCH_IN_ORDER

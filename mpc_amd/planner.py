@@ -192,6 +192,18 @@ class BatchedPlanner:
             setattr(o, name, t.data_ptr())
         return res, o
 
+    def output_views(self, out, first, count):
+        """An output set (as `_alloc_outputs` returns it) over instances [first, first + count) of
+        `out`: a sub-batch solved into it lands in the arrays of the whole batch."""
+        res_all, _ = out
+        res, o = {}, Outputs()
+        o.active_stride = self.active_stride
+        for name, t in res_all.items():
+            v = t[first:first + count]
+            res[name] = v
+            setattr(o, name, v.data_ptr())
+        return res, o
+
     def _stream(self, stream):
         if stream is None:
             stream = self._torch.cuda.current_stream(self.device)

@@ -3,7 +3,7 @@
 profiles/ directory (counter summaries, rocprofv3's kernel statistics, the decoupled workload's
 two-queue timeline, compiler-reported resource usage of every kernel).
 
-    python scripts/refresh_profiles.py profiles/r02
+    python scripts/refresh_profiles.py profiles/r02 [workload,workload...] [--resources]
 """
 import csv
 import glob
@@ -21,16 +21,17 @@ def timeline(src, dst):
     rows = [r for r in csv.DictReader(open(path)) if "mpcb::" in r["Kernel_Name"] and "ordered" not in r["Kernel_Name"]
             and "dispatch_order" not in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    # two consecutive steps from the middle of the run (two first-stage launches, X and Y axis, per step)
+    # two consecutive steps from the middle of the run (three first-stage launches per step: the two
+    # sub-batches of the X axis and the Y axis, each followed by its second-stage launch)
     zs = [i for i, r in enumerate(rows) if "zspace_kernel" in r["Kernel_Name"]]
-    first = zs[6]
-    sel = rows[first:first + 8]
+    first = zs[9]
+    sel = rows[first:first + 12]
     t0 = int(sel[0]["Start_Timestamp"])
     with open(dst, "w") as f:
         f.write("rocprofv3 --kernel-trace of `bench.py --workload decoupled` (4,096 X/Y pairs): two consecutive steps.\n"
-                "One queue (high priority) carries the X axis, the other the Y axis.  Times in microseconds from the "
-                "first kernel shown.\nThe Y axis' second-stage launch has nothing to do (no hand-overs): it only waits "
-                "for a compute unit's LDS.\n")
+                "Two queues (high priority) carry the halves of the X axis, the third the Y axis.  Times in "
+                "microseconds from the first kernel shown.\nThe Y axis' second-stage launch has nothing to do (no "
+                "hand-overs): it only waits for a compute unit's LDS.\n")
         for r in sel:
             name = re.sub(r"^.*mpcb::\(anonymous namespace\)::", "", r["Kernel_Name"])
             name = re.sub(r"\(.*$", "", name).replace("void ", "")
@@ -58,13 +59,14 @@ def resource_usage(dst):
 def main():
     dst = sys.argv[1]
     os.makedirs(dst, exist_ok=True)
-    for wl in WORKLOADS:
+    for wl in (sys.argv[2].split(",") if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else WORKLOADS):
         src = os.path.join(ROOT, "gpurun_out", "r2_prof_" + wl)
         subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "summarize_profile.py"), src,
                                os.path.join(dst, wl + "_summary.json")])
         stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
         open(os.path.join(dst, wl + "_kernel_stats.csv"), "w").write(open(stats).read())
-    timeline(os.path.join(ROOT, "gpurun_out", "r2_prof_decoupled"), os.path.join(dst, "decoupled_timeline.txt"))
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out", "r2_prof_decoupled")):
+        timeline(os.path.join(ROOT, "gpurun_out", "r2_prof_decoupled"), os.path.join(dst, "decoupled_timeline.txt"))
     if "--resources" in sys.argv:
         resource_usage(os.path.join(dst, "kernel_resource_usage.txt"))
 
