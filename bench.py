@@ -222,7 +222,7 @@ class ReplanningWorkload:
 class DecoupledWorkload:
     unit = "solves/s"
 
-    def __init__(self, B, first, dev):
+    def __init__(self, B, first, dev, split=True):
         self.N = 100
         self.B = B
         self.name = "decoupled"
@@ -236,7 +236,9 @@ class DecoupledWorkload:
         # its longest instance of the second -- so it gets high-priority streams, and it is solved as
         # X_PARTS sub-batches with a handle and a stream each: the second stage of a sub-batch starts
         # when that sub-batch's first stage is done, not the whole axis'.
-        self.parts = self.X_PARTS if B % self.X_PARTS == 0 and B >= 1024 else 1
+        # (not under a process group, whose collectives bring a stream of their own into the waits:
+        # there the axis stays one batch and the step forks from the default stream, as before)
+        self.parts = self.X_PARTS if split and B % self.X_PARTS == 0 and B >= 1024 else 1
         self.pl_more = [P.BatchedPlanner(self.N, formulation=P.BOX_1D, weight_R=1.0, device=dev)
                         for _ in range(self.parts - 1)]
         self.hi = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(self.parts)]
@@ -245,7 +247,8 @@ class DecoupledWorkload:
         # the current one): a step forks from it and joins back into it.  With the default stream
         # as a fourth party of these waits, back-to-back steps stopped making progress on a GPU box
         # with four hardware queues per process.
-        self.main_stream = self.hi[0]
+        if self.parts > 1:
+            self.main_stream = self.hi[0]
         self.ev_fork = torch.cuda.Event()
         self.ev_join = torch.cuda.Event()
         self.ev_join_x = [torch.cuda.Event() for _ in range(self.parts)]
@@ -392,7 +395,7 @@ def main():
 
     if args.workload == "decoupled":
         B = args.batch or 4096
-        wl = DecoupledWorkload(B, rank * B, dev)
+        wl = DecoupledWorkload(B, rank * B, dev, split=not distributed)
     elif args.workload == "replanning":
         B = args.batch or 16384
         wl = ReplanningWorkload(B, rank * B, dev)
