@@ -5,6 +5,7 @@ One "step" = one pass of the hot path (footstep rollout -> polygon rows -> QP so
 trajectory read-out) over one batch whose inputs already sit in HBM.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus N ...      (starts its N ranks itself: one fresh process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workloads (--workload):
@@ -416,6 +417,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    started_as_rank = "RANK" in os.environ or world > 1
+    if not started_as_rank and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: this process becomes the starter of N ranks and
+        # nothing else.  It makes no GPU call before or after (counting devices does not
+        # initialise the runtime), so no process that touched the GPU is ever replaced or forked.
+        from mpc_amd import launch
+        have = torch.cuda.device_count()
+        if have < args.gpus and args.dist_backend != "gloo":
+            sys.stderr.write("bench.py: --gpus %d asked for, %d device(s) visible; one rank per GPU needs %d "
+                             "(--dist-backend gloo lets ranks share a GPU for rehearsals)\n"
+                             % (args.gpus, have, args.gpus))
+            sys.exit(2)
+        sys.exit(launch.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    if started_as_rank and args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d does not match WORLD_SIZE=%d of the launcher\n" % (args.gpus, world))
+        sys.exit(2)
     # under torch.distributed.run (RANK and MASTER_ADDR set) the process group is used even with
     # one rank, so that a one-GPU box exercises the same code as an eight-GPU node
     distributed = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
@@ -562,6 +579,7 @@ def main():
             "value": value,
             "unit": wl.unit,
             "n_gpus": world,
+            "devices_visible": torch.cuda.device_count(),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -611,6 +629,9 @@ def main():
                                            else wl.pl.last_handover_count()),
             },
         }
+        if world > torch.cuda.device_count():
+            line["ranks_share_a_gpu"] = ("%d ranks on %d device(s) (gloo rehearsal of the N>1 code path): `value` is "
+                                         "not a scaling figure" % (world, torch.cuda.device_count()))
         if epilogue is not None:
             line["epilogue_best_cost"] = epilogue
         if longest_first is not None:

@@ -193,6 +193,31 @@ int  mpcb_solve_coupled_device_noalloc(mpcb_handle h, int32_t B, const mpcb_coup
 int  mpcb_solve_coupled_multi(const mpcb_handle *handles, int32_t n_handles, int32_t B,
                               const mpcb_coupled_inputs *in, const mpcb_outputs *out);
 
+/* The device-pointer form of mpcb_solve_coupled_multi: shard g -- B[g] instances whose inputs and
+ * outputs (DEVICE pointers on handles[g]'s device) are in[g] and out[g] -- is enqueued with
+ * handles[g] on streams[g] (a hipStream_t of that device; streams == NULL or streams[g] == NULL:
+ * that device's default stream).  Nothing is copied, no host thread is started and nothing is
+ * waited for: the call returns when every shard is enqueued, each device then works through its
+ * own shard and the caller synchronises the streams (or devices) it passed.  This is how a C
+ * caller reaches the HBM-resident rate on several GPUs at once; the handles may differ in every
+ * parameter.  No counterpart in the reference.  Returns 0 or a negative error (shards enqueued
+ * before the failing one still run). */
+int  mpcb_solve_coupled_multi_device(const mpcb_handle *handles, int32_t n_handles, const int32_t *B,
+                                     const mpcb_coupled_inputs *in, const mpcb_outputs *out,
+                                     void *const *streams);
+
+/* Several parameter groups in one call on ONE device: group g is B[g] instances solved with
+ * handles[g] (DEVICE pointers in[g], out[g]).  The reference changes horizon, weights and height
+ * from one planner object or call to the next (MPCPlanner.cpp:78-98, 493-502); a batch that mixes
+ * them is a list of groups, one handle per distinct parameter set (mpcb_create_groups builds the
+ * handles' tables together).  The groups are enqueued back to back, spread over `stream` and two
+ * library-owned streams of the device with no wait between groups -- kernels of different groups
+ * overlap and fill each other's uneven ends -- and `stream` continues only after all of them
+ * (one fork before the first group, one join after the last).  All handles must live on the same
+ * device and be distinct.  Returns 0 or a negative error. */
+int  mpcb_solve_coupled_groups(const mpcb_handle *handles, int32_t n_groups, const int32_t *B,
+                               const mpcb_coupled_inputs *in, const mpcb_outputs *out, void *stream);
+
 /* State of B receding-horizon rollouts between two replans (device pointers, updated in
  * place): what the loop of tests/replanning/testPlannerXYconstraintMPC.cpp keeps in
  * actual_state_x/y, initial_feet_x/y and replanning_schedule. */

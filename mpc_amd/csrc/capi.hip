@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -55,6 +57,18 @@ constexpr size_t SCRATCH_R_OFF = SCRATCH_J_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BY
 constexpr size_t SCRATCH_BYTES = SCRATCH_R_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BYTES; // 20.0 MiB
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 constexpr int MAX_DEVICES = 64;
+// Streams and events mpcb_solve_coupled_groups spreads its groups over besides the caller's
+// stream: two per device, created on first use and kept.  Three streams with mutual waits in all
+// -- the caller's and these two -- stay within what a process' hardware queues serve without
+// two of the parties sharing a queue.
+constexpr int GROUP_LANES = 2;
+struct GroupLanes {
+    hipStream_t stream[GROUP_LANES] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[GROUP_LANES] = {nullptr, nullptr};
+    bool ready = false;
+};
+static GroupLanes g_lanes[MAX_DEVICES];
+static std::mutex g_lanes_mutex;
 static unsigned char *g_scratch[MAX_DEVICES] = {nullptr};
 static bool g_scratch_clean[MAX_DEVICES] = {false}; // the scratch's counter block is known to be zero
 static std::mutex g_scratch_mutex;
@@ -91,6 +105,15 @@ struct mpcb_handle_s {
     // between calls (so they neither allocate nor free in steady state)
     void *stage_dev = nullptr;
     size_t stage_bytes = 0;
+    // host thread of this handle's shard in mpcb_solve_coupled_multi: started by the first such
+    // call, parked on `cv` between calls, ended by mpcb_destroy
+    struct Worker {
+        std::thread thread;
+        std::mutex m;
+        std::condition_variable cv;
+        std::function<void()> job;
+        bool has_job = false, done = false, quit = false;
+    } *worker = nullptr;
 };
 
 namespace {
@@ -195,6 +218,55 @@ int fetch_outputs(const mpcb_outputs &h, const mpcb_outputs &d, size_t B, size_t
 #undef BACK_
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
+}
+
+// Hands `job` to the handle's parked host thread (started on first use).
+void worker_submit(mpcb_handle h, std::function<void()> job) {
+    if (!h->worker) {
+        h->worker = new mpcb_handle_s::Worker();
+        mpcb_handle_s::Worker *w = h->worker;
+        w->thread = std::thread([w]() {
+            std::unique_lock<std::mutex> lock(w->m);
+            for (;;) {
+                w->cv.wait(lock, [w]() { return w->has_job || w->quit; });
+                if (w->quit) return;
+                std::function<void()> job = std::move(w->job);
+                w->has_job = false;
+                lock.unlock();
+                job();
+                lock.lock();
+                w->done = true;
+                w->cv.notify_all();
+            }
+        });
+    }
+    mpcb_handle_s::Worker *w = h->worker;
+    {
+        std::lock_guard<std::mutex> lock(w->m);
+        w->job = std::move(job);
+        w->has_job = true;
+        w->done = false;
+    }
+    w->cv.notify_all();
+}
+
+void worker_wait(mpcb_handle h) {
+    mpcb_handle_s::Worker *w = h->worker;
+    std::unique_lock<std::mutex> lock(w->m);
+    w->cv.wait(lock, [w]() { return w->done; });
+}
+
+void worker_stop(mpcb_handle h) {
+    mpcb_handle_s::Worker *w = h->worker;
+    if (!w) return;
+    {
+        std::lock_guard<std::mutex> lock(w->m);
+        w->quit = true;
+    }
+    w->cv.notify_all();
+    w->thread.join();
+    delete w;
+    h->worker = nullptr;
 }
 
 int count_not_ok(const int32_t *status, int B) {
@@ -525,6 +597,7 @@ int solve_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &ou
 
 void mpcb_destroy(mpcb_handle h) {
     if (!h) return;
+    worker_stop(h);
     {
         DeviceGuard guard(h->params.device);
         // solves still in flight on the caller's streams read the tables and write the pinned counter
@@ -730,16 +803,80 @@ int mpcb_solve_coupled_multi(const mpcb_handle *handles, int32_t n_handles, int3
         rcs[g] = mpcb_solve_coupled(handles[g], (int32_t)(last - first), &si, &so);
         if (rcs[g] < 0) msgs[g] = mpcb_last_error(); // the message is per thread: carry it over
     };
-    std::vector<std::thread> threads;
-    for (int g = 1; g < n_handles; g++) threads.emplace_back(work, g);
+    // shard 0 on the calling thread, the others on their handles' parked threads
+    for (int g = 1; g < n_handles; g++) worker_submit(handles[g], [&work, g]() { work(g); });
     work(0);
-    for (auto &t : threads) t.join();
+    for (int g = 1; g < n_handles; g++) worker_wait(handles[g]);
     int bad = 0;
     for (int g = 0; g < n_handles; g++) {
         if (rcs[g] < 0) return fail(rcs[g], "device " + std::to_string(handles[g]->params.device) + ": " + msgs[g]);
         bad += rcs[g];
     }
     return bad;
+}
+
+int mpcb_solve_coupled_multi_device(const mpcb_handle *handles, int32_t n_handles, const int32_t *B,
+                                    const mpcb_coupled_inputs *in, const mpcb_outputs *out,
+                                    void *const *streams) {
+    if (!handles || n_handles <= 0 || !B || !in || !out) return fail(MPCB_E_ARG, "null argument or no handles");
+    for (int g = 0; g < n_handles; g++) {
+        if (!handles[g]) return fail(MPCB_E_ARG, "null handle in the list");
+        if (B[g] < 0) return fail(MPCB_E_ARG, "negative shard size");
+        for (int g2 = 0; g2 < g; g2++)
+            if (handles[g2] == handles[g]) return fail(MPCB_E_ARG, "the same handle is listed twice");
+    }
+    for (int g = 0; g < n_handles; g++) {
+        const int rc = mpcb_solve_coupled_device(handles[g], B[g], &in[g], &out[g], streams ? streams[g] : nullptr);
+        if (rc < 0) return fail(rc, "shard " + std::to_string(g) + " (device " +
+                                        std::to_string(handles[g]->params.device) + "): " + g_err);
+    }
+    return 0;
+}
+
+int mpcb_solve_coupled_groups(const mpcb_handle *handles, int32_t n_groups, const int32_t *B,
+                              const mpcb_coupled_inputs *in, const mpcb_outputs *out, void *stream) {
+    if (!handles || n_groups <= 0 || !B || !in || !out) return fail(MPCB_E_ARG, "null argument or no groups");
+    for (int g = 0; g < n_groups; g++) {
+        if (!handles[g]) return fail(MPCB_E_ARG, "null handle in the list");
+        if (B[g] < 0) return fail(MPCB_E_ARG, "negative group size");
+        if (handles[g]->params.device != handles[0]->params.device)
+            return fail(MPCB_E_ARG, "the groups of one call must live on one device");
+        for (int g2 = 0; g2 < g; g2++)
+            if (handles[g2] == handles[g]) return fail(MPCB_E_ARG, "the same handle is listed twice");
+    }
+    const int dev = handles[0]->params.device;
+    if (dev >= MAX_DEVICES) return fail(MPCB_E_ARG, "device ordinal beyond the library's table");
+    DeviceGuard guard(dev);
+    GroupLanes &L = g_lanes[dev];
+    {
+        std::lock_guard<std::mutex> lock(g_lanes_mutex);
+        if (!L.ready) {
+            HIP_TRY(hipEventCreateWithFlags(&L.fork, hipEventDisableTiming));
+            for (int l = 0; l < GROUP_LANES; l++) {
+                HIP_TRY(hipStreamCreateWithFlags(&L.stream[l], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&L.join[l], hipEventDisableTiming));
+            }
+            L.ready = true;
+        }
+    }
+    hipStream_t s0 = (hipStream_t)stream;
+    const int lanes = n_groups < GROUP_LANES + 1 ? n_groups : GROUP_LANES + 1; // lane 0 is the caller's stream
+    if (lanes > 1) {
+        HIP_TRY(hipEventRecord(L.fork, s0));
+        for (int l = 1; l < lanes; l++) HIP_TRY(hipStreamWaitEvent(L.stream[l - 1], L.fork, 0));
+    }
+    int rc = 0;
+    for (int g = 0; g < n_groups && rc >= 0; g++) {
+        const int lane = g % lanes;
+        rc = mpcb_solve_coupled_device(handles[g], B[g], &in[g], &out[g], lane == 0 ? s0 : L.stream[lane - 1]);
+        if (rc < 0) fail(rc, "group " + std::to_string(g) + ": " + g_err);
+    }
+    // the join is enqueued even after a failure: what was started must not outlive the caller's order
+    for (int l = 1; l < lanes; l++) {
+        HIP_TRY(hipEventRecord(L.join[l - 1], L.stream[l - 1]));
+        HIP_TRY(hipStreamWaitEvent(s0, L.join[l - 1], 0));
+    }
+    return rc < 0 ? rc : 0;
 }
 
 int mpcb_replan_sweep_device(mpcb_handle h, int32_t B, int32_t n_stages, int32_t use_com_correction,

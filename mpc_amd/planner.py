@@ -26,7 +26,7 @@ EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constrain
            "mpcb_solve_box", "mpcb_get_matrix", "mpcb_replan_sweep_device",
            "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained", "mpcb_last_handover_count", "mpcb_last_wide_count",
            "mpcb_solve_coupled_device_noalloc", "mpcb_solve_coupled_multi", "mpcb_debug_set_stamp_buffer",
-           "mpcb_set_dispatch_hint")
+           "mpcb_set_dispatch_hint", "mpcb_solve_coupled_multi_device", "mpcb_solve_coupled_groups")
 
 
 class Params(C.Structure):
@@ -82,6 +82,11 @@ def load_library():
         lib.mpcb_solve_coupled_device_noalloc.argtypes = lib.mpcb_solve_coupled_device.argtypes
         lib.mpcb_solve_coupled_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                                                  C.POINTER(CoupledInputs), C.POINTER(Outputs)]
+        lib.mpcb_solve_coupled_multi_device.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32),
+                                                        C.POINTER(CoupledInputs), C.POINTER(Outputs),
+                                                        C.POINTER(C.c_void_p)]
+        lib.mpcb_solve_coupled_groups.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32),
+                                                  C.POINTER(CoupledInputs), C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_solve_box_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.POINTER(Outputs), C.c_void_p]
         lib.mpcb_get_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -358,6 +363,41 @@ class BatchedPlanner:
         hs = (C.c_void_p * len(planners))(*[pl._h for pl in planners])
         _check(load_library().mpcb_solve_coupled_multi(hs, len(planners), B, C.byref(ci), C.byref(o)))
         return res
+
+    @staticmethod
+    def _group_arrays(planners, prepared, outs):
+        n = len(planners)
+        hs = (C.c_void_p * n)(*[pl._h for pl in planners])
+        Bs = (C.c_int32 * n)(*[p[0] for p in prepared])
+        ins = (CoupledInputs * n)()
+        os_ = (Outputs * n)()
+        for g in range(n):
+            C.memmove(C.byref(ins[g]), C.byref(prepared[g][1]), C.sizeof(CoupledInputs))
+            C.memmove(C.byref(os_[g]), C.byref(outs[g][1]), C.sizeof(Outputs))
+        return hs, Bs, ins, os_
+
+    @staticmethod
+    def solve_coupled_multi_device(planners, prepared, outs, streams=None):
+        """Shard g = prepared[g] (from planners[g].prepare_coupled) solved with planners[g] into
+        outs[g] (from planners[g]._alloc_outputs), all enqueued by one call of
+        mpcb_solve_coupled_multi_device; streams[g] is a torch stream of planners[g]'s device or
+        None for its default stream.  Asynchronous."""
+        n = len(planners)
+        hs, Bs, ins, os_ = BatchedPlanner._group_arrays(planners, prepared, outs)
+        st = None
+        if streams is not None:
+            st = (C.c_void_p * n)(*[None if s is None else s.cuda_stream for s in streams])
+        _check(load_library().mpcb_solve_coupled_multi_device(hs, n, Bs, ins, os_, st))
+        return [o[0] for o in outs]
+
+    @staticmethod
+    def solve_coupled_groups(planners, prepared, outs, stream=None):
+        """Parameter groups of one device in one call (mpcb_solve_coupled_groups): group g is
+        prepared[g] solved with planners[g] into outs[g].  Asynchronous on `stream`."""
+        n = len(planners)
+        hs, Bs, ins, os_ = BatchedPlanner._group_arrays(planners, prepared, outs)
+        _check(load_library().mpcb_solve_coupled_groups(hs, n, Bs, ins, os_, planners[0]._stream(stream)))
+        return [o[0] for o in outs]
 
     def prepare_box(self, x0, zmin, zmax, height=None):
         f64 = self._torch.float64

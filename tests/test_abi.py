@@ -126,3 +126,55 @@ def test_eigen_overload_set_compiles():
         os.remove(obj)
     r = subprocess.run(["make", "-C", cpp, "eigen_adapter_check.o"], capture_output=True, text=True)
     assert r.returncode == 0 and os.path.exists(obj), r.stdout + r.stderr
+
+
+_RANK_WORKER = r"""
+import os, sys
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert int(os.environ["LOCAL_RANK"]) == rank and os.environ["MASTER_ADDR"] == "127.0.0.1"
+t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+dist.all_reduce(t)
+if len(sys.argv) > 1 and sys.argv[1] == "fail" and rank == 1:
+    sys.exit(7)   # before the barrier: rank 0 would wait for ever if nobody ended it
+dist.barrier()
+if rank == 0:
+    print("sum=%d world=%d" % (int(t.item()), world))
+dist.destroy_process_group()
+"""
+
+
+def test_self_launch_starts_ranks_and_relays_rank0(tmp_path):
+    """The starter bench.py uses for `--gpus N` without torch.distributed.run: N fresh processes
+    with the env:// rendezvous variables, rank 0's standard output relayed, a failing rank ends
+    the job with its code."""
+    import io
+    from mpc_amd import launch
+    script = tmp_path / "rank_worker.py"
+    script.write_text(_RANK_WORKER)
+    out, err = io.StringIO(), io.StringIO()
+    rc = launch.spawn_ranks(3, [sys.executable, str(script)], out=out, err=err, timeout=240)
+    assert rc == 0, err.getvalue()
+    # (gloo announces its connections on standard output; the worker's own line is the last)
+    assert out.getvalue().strip().splitlines()[-1] == "sum=6 world=3"
+    out, err = io.StringIO(), io.StringIO()
+    rc = launch.spawn_ranks(2, [sys.executable, str(script), "fail"], out=out, err=err, timeout=240)
+    assert rc == 7 and "sum=" not in out.getvalue()
+
+
+def test_bench_gpus_flag_is_honoured_or_refused():
+    """`bench.py --gpus 2` must never silently measure one GPU: without two devices (and without
+    the gloo rehearsal backend) it exits non-zero before touching a GPU; under a launcher whose
+    WORLD_SIZE disagrees with --gpus it refuses as well."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs are present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 2" in r.stderr and r.stdout == ""
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
