@@ -45,6 +45,12 @@ enum {
 
 enum { MPCB_MODE_AUTO = 0, MPCB_MODE_DENSE = 1 };
 
+/* Where the instance-independent tables of a handle are built (mpcb_params.table_build). */
+enum {
+    MPCB_TABLES_DEVICE = 0, /* on the GPU, double-double arithmetic (default)                  */
+    MPCB_TABLES_HOST   = 1  /* on the host in long double, one thread: the checker of the above */
+};
+
 /* Per-instance status written to mpcb_outputs.status. */
 enum {
     MPCB_OK         = 0,
@@ -89,6 +95,7 @@ typedef struct {
     int32_t solver_mode;        /* MPCB_MODE_AUTO: structure-exploiting kernel first, dense
                                    kernel for what it hands over; MPCB_MODE_DENSE: every
                                    instance through the dense kernel (slow; cross-check)   */
+    int32_t table_build;        /* MPCB_TABLES_DEVICE (default) or MPCB_TABLES_HOST        */
 } mpcb_params;
 
 typedef struct mpcb_handle_s *mpcb_handle;
@@ -116,9 +123,13 @@ typedef struct {
     const double  *zref_phase; /* [B][nphase][2] or NULL                                 */
     /* Optional CoM height per instance: the `actual_height` argument the reference takes on
      * every solve call (MPCPlanner.cpp:493-502,516).  NULL = mpcb_params.height for all.
-     * Available for COUPLED_JERK and COUPLED_VEL (their Hessian does not depend on the
-     * height, so one handle serves every height); COUPLED_REF keeps the per-handle height.
-     * The first call that passes heights builds a few more tables (one-off, ~0.1 s).      */
+     * COUPLED_JERK and COUPLED_VEL: their Hessian does not depend on the height, so one
+     * handle serves every height (any entry point).  COUPLED_REF: the Hessian contains
+     * Qs Zu'Zu, so every distinct height is a parameter group of its own; the host-pointer
+     * entry point mpcb_solve_coupled sorts the instances by height, builds the tables of
+     * heights it has not seen before (together, on the GPU; at most 1024 are kept) and
+     * solves the groups in one go; the device-pointer entry points take such a batch as
+     * explicit groups (mpcb_create_groups + mpcb_solve_coupled_groups).                    */
     const double  *height;     /* [B] or NULL                                             */
     /* Optional ZMP reference for COUPLED_REF that changes from knot to knot: the zmp_ref_x,
      * zmp_ref_y vectors of solveQPConstraintCoupledRef (MPCPlanner.cpp:632-640), any values.
@@ -150,9 +161,17 @@ typedef struct {
                                           rows first), the `slacks` member of MPCPlanner.h:191 */
 } mpcb_outputs;
 
-/* Builds every instance-independent matrix (prediction matrices, condensed
- * Hessian, its factor and the response matrices) and uploads them. */
+/* Builds every instance-independent matrix of one parameter set -- what MPCPlanner::buildMatrix
+ * (MPCPlanner.cpp:101-156), the Hessian assembly of the solve methods (:233, :523-559, :723-739)
+ * and the factorisation inside solve_quadprog (eiquadprog.hpp:165-176) recompute on every call:
+ * prediction matrices, condensed Hessian block, its Cholesky factor, L^-T and the response
+ * matrices -- on the GPU (mpcb_params.table_build). */
 int  mpcb_create(const mpcb_params *params, mpcb_handle *out);
+/* The same for n parameter sets at once (horizons, weights, heights, formulations may all differ;
+ * one device): the tables of all of them are built by one chain of launches, one grid row per
+ * set, so a sweep over H heights or weights costs about what one set costs.  out[0..n) receive
+ * the handles; on failure none is created.  Each handle is destroyed with mpcb_destroy. */
+int  mpcb_create_groups(const mpcb_params *params, int32_t n, mpcb_handle *out);
 void mpcb_destroy(mpcb_handle h);
 const char *mpcb_last_error(void);
 
@@ -300,8 +319,21 @@ int  mpcb_debug_set_stamp_buffer(mpcb_handle h, long long *dev);
 
 /* Copy an instance-independent matrix to the host (tests, diagnostics).
  * which: 0 = S (ZMP response, N x N), 1 = W^T (jerk response), 2 = CoM position
- * response, 3 = CoM velocity response, 4 = Kz (N x 4), 5 = Kx (N x 4).      */
+ * response, 3 = CoM velocity response, 4 = Kz (N x 4), 5 = Kx (N x 4); the prediction
+ * matrices of buildMatrix: 6 = first column of Zu (N), 7 = Zx (N x 3), 8 / 9 = the same for
+ * Xpu / Xpx, 10 / 11 = for Xvu / Xvx; 12 = L^-T of the Hessian block (N x N, column-major);
+ * 13 = f_unc matrix F (4 x 4); COUPLED_REF: 14 = Sp, 15 = Wp (nphase x N), 16 = F2
+ * (4 x nphase), 17 = F3 (nphase x nphase); handles that take per-instance heights:
+ * 18 = Spp, 19 = Sps, 20 = Saa, 21 = Wtp, 22 = Wta (N x N), 23 = Kzp, 24 = Kza (N x 4).
+ * Returns the number of doubles written (dst == NULL: only that number) or a negative error. */
 int  mpcb_get_matrix(mpcb_handle h, int32_t which, double *dst);
+
+/* Diagnostic, needs no GPU: the same matrix from the host long-double construction (what a
+ * handle created with MPCB_TABLES_HOST uploads), computed on the spot for `params`.  Ids as
+ * mpcb_get_matrix (0-17; the height-free parts 18-24 are not offered); 25 = {trace(G1),
+ * trace(L^-T)}.  The checker of the GPU construction; no counterpart in the reference.
+ * Returns the number of doubles written (dst == NULL: only that number) or a negative error. */
+int  mpcb_debug_host_table(const mpcb_params *params, int32_t which, double *dst);
 
 #ifdef __cplusplus
 }

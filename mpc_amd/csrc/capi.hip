@@ -5,14 +5,19 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <algorithm>
+#include <cstdint>
 #include <functional>
+#include <map>
 #include <mutex>
+#include <numeric>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "kernels.h"
 #include "setup.h"
+#include "tables.h"
 
 namespace {
 
@@ -98,7 +103,12 @@ struct mpcb_handle_s {
     // dense kernel's last workgroup stores to (DenseWs::host_count); read, without waiting, at the
     // start of a solve to size the dense workspace
     int *count_host = nullptr;
-    hipStream_t own_stream = nullptr; // stream of the host-pointer entry points
+    hipStream_t own_stream = nullptr; // stream of the host-pointer entry points (created by the first of them)
+    // COUPLED_REF handles of other CoM heights (same parameters otherwise), keyed by the bits of
+    // the height: a host-pointer batch that brings per-instance heights is split over them
+    std::map<uint64_t, mpcb_handle> by_height;
+    std::map<uint64_t, uint64_t> height_used; // call number of the last use (for eviction)
+    uint64_t height_calls = 0;
     // COUPLED_REF with a free (per-knot) ZMP reference: Sp, Wp, F2, F3 with one segment per knot
     const double *knot_Sp = nullptr, *knot_Wp = nullptr, *knot_F2 = nullptr, *knot_F3 = nullptr;
     // device arena of the host-pointer entry points: grown when a batch needs more, kept
@@ -138,6 +148,11 @@ struct DeviceGuard {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
+
+int ensure_own_stream(mpcb_handle h) {
+    if (!h->own_stream) HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    return 0;
+}
 
 // Scratch copies for the host-pointer entry points.
 // Device copies of host arrays, carved out of the handle's arena.  The staging sequence of an
@@ -282,42 +297,78 @@ extern "C" {
 
 const char *mpcb_last_error(void) { return g_err.c_str(); }
 
-int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
-    if (!params || !out) return fail(MPCB_E_ARG, "null argument");
+// Host part of a handle: parameters checked, layout of one QP.
+static int create_begin(const mpcb_params *params, mpcb_handle *out) {
     *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(MPCB_E_NOGPU, "no HIP device available");
-    if (params->device < 0 || params->device >= ndev) return fail(MPCB_E_ARG, "device ordinal out of range");
     mpcb_handle h = new mpcb_handle_s();
     h->params = *params;
     const char *err = "";
-    int rc = mpcb::build_setup(*params, h->hs, &err);
+    int rc = mpcb::build_layout(*params, h->hs, &err);
+    if (rc == 0 && params->table_build != MPCB_TABLES_DEVICE && params->table_build != MPCB_TABLES_HOST) {
+        rc = MPCB_E_ARG;
+        err = "table_build must be MPCB_TABLES_DEVICE or MPCB_TABLES_HOST";
+    }
     if (rc) {
         delete h;
         return fail(rc, err);
     }
-    DeviceGuard guard(params->device);
-    if (!guard.ok) {
-        delete h;
-        return fail(MPCB_E_HIP, "hipSetDevice failed");
-    }
+    *out = h;
+    return 0;
+}
+
+// Points the kernels' argument blocks at tables built on the device.
+static void adopt_tables(mpcb_handle h, const mpcb::TableSet &t) {
+    mpcb::DevSetup &ds = h->ds;
+    h->dev_allocs.push_back(t.block);
+    ds.S = t.S; ds.Wt = t.Wt; ds.Sc = t.Sc; ds.Sv = t.Sv;
+    ds.Kx = t.Kx; ds.Kz = t.Kz; ds.Kc = t.Kc; ds.Kv = t.Kv;
+    ds.Sp = t.Sp; ds.Wp = t.Wp; ds.F2 = t.F2; ds.F3 = t.F3;
+    ds.Spp = t.Spp; ds.Sps = t.Sps; ds.Saa = t.Saa; ds.Wtp = t.Wtp; ds.Wta = t.Wta;
+    ds.Kzp = t.Kzp; ds.Kza = t.Kza;
+    h->ws.J1 = t.J0;
+    h->ws.zu_col = t.zu_col; h->ws.xp_col = t.xp_col; h->ws.xv_col = t.xv_col;
+    h->ws.zx = t.zx; h->ws.xpx = t.xpx; h->ws.xvx = t.xvx;
+    std::memcpy(h->hs.F, t.F, sizeof(h->hs.F));
+    mpcb::finish_scalars(h->params, h->hs, t.traceG1, t.traceJ1);
+}
+
+// Everything after the tables: scalars of the argument blocks, bookkeeping arrays, counters,
+// stream.  `tables` = the device-built tables, or NULL to build them on the host (the checker).
+static int create_finish(mpcb_handle h, const mpcb::TableSet *tables) {
+    const mpcb_params *params = &h->params;
+    int rc = 0;
     if (params->device < MAX_DEVICES) {
         // address of this device's copy of the scratch array (see its declaration)
         std::lock_guard<std::mutex> lock(g_scratch_mutex);
         if (!g_scratch[params->device]) {
             unsigned char *ptr = nullptr;
             hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
-            if (e != hipSuccess || !ptr) {
-                delete h;
+            if (e != hipSuccess || !ptr)
                 return fail(MPCB_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
-            }
             g_scratch[params->device] = ptr;
         }
     }
-    const mpcb::HostSetup &hs = h->hs;
+    mpcb::HostSetup &hs = h->hs;
     mpcb::DevSetup &ds = h->ds;
     std::memset(&ds, 0, sizeof(ds));
+    std::memset(&h->ws, 0, sizeof(h->ws));
+    if (tables) {
+        adopt_tables(h, *tables);
+    } else {
+        const char *err = "";
+        if ((rc = mpcb::build_tables_host(*params, hs, &err))) return fail(rc, err);
+        if ((rc = upload_to(h, hs.S, &ds.S)) || (rc = upload_to(h, hs.Wt, &ds.Wt)) ||
+            (rc = upload_to(h, hs.Sc, &ds.Sc)) || (rc = upload_to(h, hs.Sv, &ds.Sv)) ||
+            (rc = upload_to(h, hs.Kx, &ds.Kx)) || (rc = upload_to(h, hs.Kz, &ds.Kz)) ||
+            (rc = upload_to(h, hs.Kc, &ds.Kc)) || (rc = upload_to(h, hs.Kv, &ds.Kv)) ||
+            (rc = upload_to(h, hs.Sp, &ds.Sp)) || (rc = upload_to(h, hs.Wp, &ds.Wp)) ||
+            (rc = upload_to(h, hs.F2, &ds.F2)) || (rc = upload_to(h, hs.F3, &ds.F3)) ||
+            (rc = upload_to(h, hs.J0, &h->ws.J1)) || (rc = upload_to(h, hs.zu_col, &h->ws.zu_col)) ||
+            (rc = upload_to(h, hs.xp_col, &h->ws.xp_col)) || (rc = upload_to(h, hs.xv_col, &h->ws.xv_col)) ||
+            (rc = upload_to(h, hs.zx, &h->ws.zx)) || (rc = upload_to(h, hs.xpx, &h->ws.xpx)) ||
+            (rc = upload_to(h, hs.xvx, &h->ws.xvx)))
+            return rc;
+    }
     ds.N = hs.N;
     ds.m = hs.m;
     ds.axes = hs.axes;
@@ -337,61 +388,103 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
     ds.Ts = params->Ts;
     ds.inv_gravity = 1.0 / params->gravity;
     std::memcpy(ds.hip, params->hip_offsets, sizeof(ds.hip));
-    if ((rc = upload_to(h, hs.S, &ds.S)) || (rc = upload_to(h, hs.Wt, &ds.Wt)) ||
-        (rc = upload_to(h, hs.Sc, &ds.Sc)) || (rc = upload_to(h, hs.Sv, &ds.Sv)) ||
-        (rc = upload_to(h, hs.Kx, &ds.Kx)) || (rc = upload_to(h, hs.Kz, &ds.Kz)) ||
-        (rc = upload_to(h, hs.Kc, &ds.Kc)) || (rc = upload_to(h, hs.Kv, &ds.Kv)) ||
-        (rc = upload_to(h, hs.Sp, &ds.Sp)) || (rc = upload_to(h, hs.Wp, &ds.Wp)) ||
-        (rc = upload_to(h, hs.F2, &ds.F2)) || (rc = upload_to(h, hs.F3, &ds.F3)) ||
-        (rc = upload_to(h, hs.knot_phase, &ds.knot_phase)) ||
-        (rc = upload_to(h, hs.knot_row0, &ds.knot_row0))) {
-        mpcb_destroy(h);
+    if ((rc = upload_to(h, hs.knot_phase, &ds.knot_phase)) || (rc = upload_to(h, hs.knot_row0, &ds.knot_row0)) ||
+        (rc = upload_to(h, hs.row_knot, &h->ws.row_knot)) || (rc = upload_to(h, hs.row_slot, &h->ws.row_slot)))
         return rc;
-    }
-    std::memset(&h->ws, 0, sizeof(h->ws));
-    if ((rc = upload_to(h, hs.J0, &h->ws.J1)) || (rc = upload_to(h, hs.zu_col, &h->ws.zu_col)) ||
-        (rc = upload_to(h, hs.xp_col, &h->ws.xp_col)) || (rc = upload_to(h, hs.xv_col, &h->ws.xv_col)) ||
-        (rc = upload_to(h, hs.zx, &h->ws.zx)) || (rc = upload_to(h, hs.xpx, &h->ws.xpx)) ||
-        (rc = upload_to(h, hs.xvx, &h->ws.xvx)) || (rc = upload_to(h, hs.row_knot, &h->ws.row_knot)) ||
-        (rc = upload_to(h, hs.row_slot, &h->ws.row_slot))) {
-        mpcb_destroy(h);
-        return rc;
-    }
     {
         int *cnt = nullptr;
-        if (hipMalloc((void **)&cnt, mpcb::COUNTER_INTS * sizeof(int)) != hipSuccess) { // the counter block (kernels.h)
-            mpcb_destroy(h);
+        if (hipMalloc((void **)&cnt, mpcb::COUNTER_INTS * sizeof(int)) != hipSuccess) // the counter block (kernels.h)
             return fail(MPCB_E_HIP, "hipMalloc failed");
-        }
         h->dev_allocs.push_back(cnt);
         h->ws.count = cnt;
         h->ws.wide_count = cnt + mpcb::CNT_WIDE;
     }
     if (params->formulation != MPCB_UNCONSTRAINED) {
-        // the dense kernel's LDS carve-up must fit a workgroup: found out here, not at the
-        // first solve
-        const size_t lds = mpcb::dense_lds_bytes_needed(ds, &h->dense_in_lds);
+        // The kernels' LDS carve-ups must fit a workgroup: found out here, not at the first solve.
+        // A COUPLED_REF handle may later be given a per-knot ZMP reference, whose segments are the
+        // N knots instead of the footstep phases: sized for the larger of the two.
+        mpcb::DevSetup sized = ds;
+        if (params->formulation == MPCB_COUPLED_REF && sized.N > sized.nref) sized.nref = sized.N;
+        const size_t lds = mpcb::dense_lds_bytes_needed(sized, &h->dense_in_lds);
         h->wide_fits = params->formulation != MPCB_BOX_1D && params->formulation != MPCB_BOX_SLACK &&
-                       mpcb::zspace_wide_lds_bytes(ds) <= 160 * 1024 - 256;
-        if (lds > 160 * 1024) {
-            mpcb_destroy(h);
+                       mpcb::zspace_wide_lds_bytes(sized) <= 160 * 1024 - 256;
+        if (lds > 160 * 1024)
             return fail(MPCB_E_ARG, "horizon / number_of_steps too large for this formulation: the dense "
                                     "second-stage kernel would need " + std::to_string(lds) +
                                     " bytes of LDS per workgroup (limit 163840)");
+    }
+    if (hipHostMalloc((void **)&h->count_host, sizeof(int), hipHostMallocMapped) != hipSuccess)
+        return fail(MPCB_E_HIP, "allocating the handle's pinned counter failed");
+    *h->count_host = 0;
+    if (hipHostGetDevicePointer((void **)&h->ws.host_count, h->count_host, 0) != hipSuccess)
+        return fail(MPCB_E_HIP, "hipHostGetDevicePointer failed");
+    return 0;
+}
+
+int mpcb_create_groups(const mpcb_params *params, int32_t n, mpcb_handle *out) {
+    if (!params || !out || n <= 0) return fail(MPCB_E_ARG, "null argument or no parameter sets");
+    for (int q = 0; q < n; q++) out[q] = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MPCB_E_NOGPU, "no HIP device available");
+    const int dev = params[0].device;
+    if (dev < 0 || dev >= ndev) return fail(MPCB_E_ARG, "device ordinal out of range");
+    for (int q = 1; q < n; q++)
+        if (params[q].device != dev) return fail(MPCB_E_ARG, "the parameter sets of one call must name one device");
+    int rc = 0;
+    auto undo = [&](int code) {
+        const std::string msg = g_err;
+        for (int q = 0; q < n; q++) {
+            if (out[q]) mpcb_destroy(out[q]);
+            out[q] = nullptr;
+        }
+        g_err = msg;
+        return code;
+    };
+    for (int q = 0; q < n; q++)
+        if ((rc = create_begin(&params[q], &out[q]))) {
+            if (n > 1) g_err = "parameter set " + std::to_string(q) + ": " + g_err;
+            return undo(rc);
+        }
+    DeviceGuard guard(dev);
+    if (!guard.ok) {
+        fail(MPCB_E_HIP, "hipSetDevice failed");
+        return undo(MPCB_E_HIP);
+    }
+    // the tables of every set that asks for the device build: one chain of launches
+    std::vector<int> which;
+    std::vector<mpcb::TableSpec> specs;
+    for (int q = 0; q < n; q++)
+        if (params[q].table_build == MPCB_TABLES_DEVICE) {
+            which.push_back(q);
+            specs.emplace_back();
+            mpcb::table_spec(params[q], out[q]->hs, specs.back());
+        }
+    std::vector<mpcb::TableSet> sets(specs.size());
+    if (!specs.empty()) {
+        std::string err;
+        if ((rc = mpcb::build_tables_device(specs.data(), (int)specs.size(), sets.data(), nullptr, &err))) {
+            fail(rc, err);
+            return undo(rc);
         }
     }
-    if (hipHostMalloc((void **)&h->count_host, sizeof(int), hipHostMallocMapped) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
-        mpcb_destroy(h);
-        return fail(MPCB_E_HIP, "creating the handle's stream or pinned counter failed");
-    }
-    *h->count_host = 0;
-    if (hipHostGetDevicePointer((void **)&h->ws.host_count, h->count_host, 0) != hipSuccess) {
-        mpcb_destroy(h);
-        return fail(MPCB_E_HIP, "hipHostGetDevicePointer failed");
-    }
-    *out = h;
+    std::vector<const mpcb::TableSet *> mine(n, nullptr);
+    for (size_t k = 0; k < which.size(); k++) mine[which[k]] = &sets[k];
+    for (int q = 0; q < n; q++)
+        if ((rc = create_finish(out[q], mine[q]))) {
+            // tables not yet adopted by a handle are still ours to free
+            for (int r = q; r < n; r++)
+                if (mine[r] && mine[r]->block &&
+                    (r > q || out[q]->dev_allocs.empty() || out[q]->dev_allocs.front() != mine[r]->block))
+                    (void)hipFree(mine[r]->block);
+            return undo(rc);
+        }
     return 0;
+}
+
+int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
+    if (!params || !out) return fail(MPCB_E_ARG, "null argument");
+    return mpcb_create_groups(params, 1, out);
 }
 
 namespace {
@@ -477,7 +570,7 @@ int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
 // Builds and uploads the height-free response tables the first time a batch brings its own
 // heights (one-off host work and allocations, like mpcb_create's).
 int ensure_height_tables(mpcb_handle h) {
-    if (h->ds.Spp) return 0;
+    if (h->ds.Spp) return 0; // (handles whose tables were built on the device have them from the start)
     const char *err = "";
     int rc = mpcb::build_height_tables(h->params, h->hs, &err);
     if (rc) return fail(rc, err);
@@ -497,22 +590,18 @@ int ensure_height_tables(mpcb_handle h) {
 // Built and uploaded the first time such a reference is passed.
 int ensure_knot_reference_tables(mpcb_handle h) {
     if (h->knot_Sp) return 0;
-    const mpcb::HostSetup &hs = h->hs;
-    const size_t N = (size_t)hs.N;
-    const double Qs = h->params.weight_Qs;
-    std::vector<double> Sp(N * N), Wp(N * N), F2(4 * N), F3(N * N);
-    for (size_t i = 0; i < N * N; i++) {
-        Sp[i] = Qs * hs.S[i];
-        Wp[i] = Qs * hs.Wt[i];
-        F3[i] = -Qs * Qs * hs.S[i] / 2;
-    }
-    for (size_t k = 0; k < N; k++)
-        for (size_t a = 0; a < 4; a++)
-            F2[a * N + k] = -Qs * (hs.Kz[k * 4 + a] - (a < 3 ? hs.zx[k * 3 + a] : 0.0));
-    int rc;
-    if ((rc = upload_to(h, Wp, &h->knot_Wp)) || (rc = upload_to(h, F2, &h->knot_F2)) ||
-        (rc = upload_to(h, F3, &h->knot_F3)) || (rc = upload_to(h, Sp, &h->knot_Sp)))
-        return rc;
+    const size_t N = (size_t)h->hs.N;
+    double *blk = nullptr;
+    HIP_TRY(hipMalloc((void **)&blk, (3 * N * N + 4 * N) * sizeof(double)));
+    h->dev_allocs.push_back(blk);
+    double *Sp = blk, *Wp = blk + N * N, *F3 = blk + 2 * N * N, *F2 = blk + 3 * N * N;
+    HIP_TRY(mpcb::launch_knot_reference_tables((int)N, h->params.weight_Qs, h->ds.S, h->ds.Wt, h->ds.Kz, h->ws.zx,
+                                               Sp, Wp, F2, F3, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    h->knot_Wp = Wp;
+    h->knot_F2 = F2;
+    h->knot_F3 = F3;
+    h->knot_Sp = Sp;
     return 0;
 }
 
@@ -598,6 +687,8 @@ int solve_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &ou
 void mpcb_destroy(mpcb_handle h) {
     if (!h) return;
     worker_stop(h);
+    for (auto &kv : h->by_height) mpcb_destroy(kv.second);
+    h->by_height.clear();
     {
         DeviceGuard guard(h->params.device);
         // solves still in flight on the caller's streams read the tables and write the pinned counter
@@ -667,9 +758,58 @@ int mpcb_last_handover_count(mpcb_handle h) {
 }
 
 int mpcb_get_matrix(mpcb_handle h, int32_t which, double *dst) {
-    if (!h || !dst) return fail(MPCB_E_ARG, "null argument");
-    const mpcb::HostSetup &hs = h->hs;
+    if (!h) return fail(MPCB_E_ARG, "null argument");
+    const mpcb::DevSetup &ds = h->ds;
+    const size_t N = (size_t)h->hs.N, P = (size_t)h->hs.nphase;
+    const double *src = nullptr;
+    size_t count = 0;
+    switch (which) {
+    case 0: src = ds.S; count = N * N; break;
+    case 1: src = ds.Wt; count = N * N; break;
+    case 2: src = ds.Sc; count = N * N; break;
+    case 3: src = ds.Sv; count = N * N; break;
+    case 4: src = ds.Kz; count = N * 4; break;
+    case 5: src = ds.Kx; count = N * 4; break;
+    case 6: src = h->ws.zu_col; count = N; break;
+    case 7: src = h->ws.zx; count = N * 3; break;
+    case 8: src = h->ws.xp_col; count = N; break;
+    case 9: src = h->ws.xpx; count = N * 3; break;
+    case 10: src = h->ws.xv_col; count = N; break;
+    case 11: src = h->ws.xvx; count = N * 3; break;
+    case 12: src = h->ws.J1; count = N * N; break;
+    case 13:
+        if (dst) std::memcpy(dst, ds.F, sizeof(ds.F));
+        return 16;
+    case 14: src = ds.Sp; count = P * N; break;
+    case 15: src = ds.Wp; count = P * N; break;
+    case 16: src = ds.F2; count = 4 * P; break;
+    case 17: src = ds.F3; count = P * P; break;
+    case 18: src = ds.Spp; count = N * N; break;
+    case 19: src = ds.Sps; count = N * N; break;
+    case 20: src = ds.Saa; count = N * N; break;
+    case 21: src = ds.Wtp; count = N * N; break;
+    case 22: src = ds.Wta; count = N * N; break;
+    case 23: src = ds.Kzp; count = N * 4; break;
+    case 24: src = ds.Kza; count = N * 4; break;
+    default: return fail(MPCB_E_ARG, "unknown matrix id");
+    }
+    if (!src) return fail(MPCB_E_ARG, "this handle does not hold that matrix");
+    if (dst) {
+        DeviceGuard guard(h->params.device);
+        HIP_TRY(hipMemcpy(dst, src, count * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return (int)count;
+}
+
+int mpcb_debug_host_table(const mpcb_params *params, int32_t which, double *dst) {
+    if (!params) return fail(MPCB_E_ARG, "null argument");
+    mpcb::HostSetup hs;
+    const char *err = "";
+    int rc = mpcb::build_layout(*params, hs, &err);
+    if (!rc) rc = mpcb::build_tables_host(*params, hs, &err);
+    if (rc) return fail(rc, err);
     const std::vector<double> *src = nullptr;
+    std::vector<double> tmp;
     switch (which) {
     case 0: src = &hs.S; break;
     case 1: src = &hs.Wt; break;
@@ -677,10 +817,23 @@ int mpcb_get_matrix(mpcb_handle h, int32_t which, double *dst) {
     case 3: src = &hs.Sv; break;
     case 4: src = &hs.Kz; break;
     case 5: src = &hs.Kx; break;
+    case 6: src = &hs.zu_col; break;
+    case 7: src = &hs.zx; break;
+    case 8: src = &hs.xp_col; break;
+    case 9: src = &hs.xpx; break;
+    case 10: src = &hs.xv_col; break;
+    case 11: src = &hs.xvx; break;
+    case 12: src = &hs.J0; break;
+    case 13: tmp.assign(hs.F, hs.F + 16); src = &tmp; break;
+    case 14: src = &hs.Sp; break;
+    case 15: src = &hs.Wp; break;
+    case 16: src = &hs.F2; break;
+    case 17: src = &hs.F3; break;
+    case 25: tmp = {hs.traceG1, hs.c2 / hs.axes}; src = &tmp; break;
     default: return fail(MPCB_E_ARG, "unknown matrix id");
     }
-    std::memcpy(dst, src->data(), src->size() * sizeof(double));
-    return 0;
+    if (dst) std::memcpy(dst, src->data(), src->size() * sizeof(double));
+    return (int)src->size();
 }
 
 // argument checks shared by the coupled entry points; fills the kernels' input block
@@ -716,7 +869,9 @@ static int coupled_arguments(mpcb_handle h, int32_t B, const mpcb_coupled_inputs
     if (in->rows_pqr && form == MPCB_COUPLED_REF && !in->zref_phase && !in->zref_knot)
         return fail(MPCB_E_ARG, "COUPLED_REF with rows_pqr needs zref_phase or zref_knot");
     if (in->height && form == MPCB_COUPLED_REF)
-        return fail(MPCB_E_ARG, "COUPLED_REF takes its height from mpcb_params: its Hessian depends on it");
+        return fail(MPCB_E_ARG, "COUPLED_REF with per-instance heights: the Hessian depends on the height, so every "
+                                "distinct height is a parameter group -- use mpcb_solve_coupled (host pointers, groups "
+                                "the instances itself) or mpcb_create_groups + mpcb_solve_coupled_groups");
     return 0;
 }
 
@@ -986,6 +1141,7 @@ int mpcb_solve_unconstrained(mpcb_handle h, int32_t B, const double *x0, const d
                              const mpcb_outputs *out) {
     if (!h || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
     DeviceGuard guard(h->params.device);
+    if (int rc0 = ensure_own_stream(h)) return rc0;
     Staging st(h);
     const double *dx0, *dz;
     int rc;
@@ -1001,9 +1157,166 @@ int mpcb_solve_unconstrained(mpcb_handle h, int32_t B, const double *x0, const d
     return 0;
 }
 
+// COUPLED_REF with a CoM height per instance (host pointers).  The Hessian of this form contains
+// Qs Zu' Zu and Zu depends on the height (MPCPlanner.cpp:658, 728-729), so every distinct height
+// is a parameter group of its own: the instances are sorted by height, the handles of heights
+// not seen before are created together (one chain of table-building launches), the groups are
+// solved by one mpcb_solve_coupled_groups call and the results go back in the caller's order.
+constexpr size_t MAX_HEIGHT_HANDLES = 1024;
+
+static int solve_coupled_by_height(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, const mpcb_outputs *out) {
+    const size_t b = (size_t)B, N = (size_t)h->hs.N, m = (size_t)h->hs.m, P = (size_t)h->hs.nphase;
+    const size_t as = out->active_stride > 0 ? (size_t)out->active_stride : 0;
+    for (size_t i = 0; i < b; i++)
+        if (!(in->height[i] > 0)) return fail(MPCB_E_ARG, "height must be positive for every instance");
+    std::vector<int> perm(b);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int c) { return in->height[a] < in->height[c]; });
+    std::vector<double> gh;   // height of every group
+    std::vector<int32_t> gB;  // its size
+    for (size_t k = 0; k < b; k++) {
+        const double v = in->height[perm[k]];
+        if (gh.empty() || gh.back() != v) {
+            gh.push_back(v);
+            gB.push_back(0);
+        }
+        gB.back()++;
+    }
+    if (gh.size() > MAX_HEIGHT_HANDLES)
+        return fail(MPCB_E_ARG, "more than " + std::to_string(MAX_HEIGHT_HANDLES) + " distinct heights in one batch");
+    auto key = [](double v) {
+        uint64_t k;
+        std::memcpy(&k, &v, sizeof(k));
+        return k;
+    };
+    h->height_calls++;
+    // handles of the heights this call needs and the handle does not have yet: built together
+    std::vector<mpcb_params> fresh;
+    for (double v : gh)
+        if (v != h->params.height && !h->by_height.count(key(v))) {
+            fresh.push_back(h->params);
+            fresh.back().height = v;
+        }
+    if (h->by_height.size() + fresh.size() > MAX_HEIGHT_HANDLES) {
+        // make room: drop the handles that were used longest ago (none of this call's)
+        std::vector<std::pair<uint64_t, uint64_t>> age; // (last use, key)
+        for (auto &kv : h->by_height) age.emplace_back(h->height_used[kv.first], kv.first);
+        std::sort(age.begin(), age.end());
+        HIP_TRY(hipDeviceSynchronize());
+        for (auto &a : age) {
+            if (h->by_height.size() + fresh.size() <= MAX_HEIGHT_HANDLES) break;
+            bool needed = false;
+            for (double v : gh) needed = needed || key(v) == a.second;
+            if (needed) continue;
+            mpcb_destroy(h->by_height[a.second]);
+            h->by_height.erase(a.second);
+            h->height_used.erase(a.second);
+        }
+    }
+    if (!fresh.empty()) {
+        std::vector<mpcb_handle> made(fresh.size(), nullptr);
+        int rc = mpcb_create_groups(fresh.data(), (int32_t)fresh.size(), made.data());
+        if (rc) return rc;
+        for (size_t k = 0; k < fresh.size(); k++) h->by_height[key(fresh[k].height)] = made[k];
+    }
+    std::vector<mpcb_handle> gH(gh.size());
+    for (size_t g = 0; g < gh.size(); g++) {
+        gH[g] = gh[g] == h->params.height ? h : h->by_height[key(gh[g])];
+        h->height_used[key(gh[g])] = h->height_calls;
+    }
+    // inputs in group order
+    auto gather = [&](const auto *src, size_t w, auto &dst) {
+        if (!src) return;
+        dst.resize(b * w);
+        for (size_t k = 0; k < b; k++) std::memcpy(&dst[k * w], src + (size_t)perm[k] * w, w * sizeof(*src));
+    };
+    std::vector<double> x0, y0, speed, feet_x, feet_y, com0, rows_pqr, zref_phase, zref_knot;
+    std::vector<int32_t> swing0;
+    gather(in->x0, 3, x0); gather(in->y0, 3, y0); gather(in->speed, 2, speed);
+    gather(in->feet_x, 4, feet_x); gather(in->feet_y, 4, feet_y); gather(in->swing0, 1, swing0);
+    gather(in->com0, 2, com0); gather(in->rows_pqr, m * 3, rows_pqr); gather(in->zref_phase, P * 2, zref_phase);
+    gather(in->zref_knot, N * 2, zref_knot);
+    // outputs in group order (host side), scattered back at the end
+    std::vector<double> o_d[13];
+    std::vector<int32_t> o_i[4];
+    mpcb_outputs hp = *out; // host, permuted
+    {
+        int kd = 0, ki = 0;
+#define OD_(field, w) if (out->field) { o_d[kd].resize(b * (w)); hp.field = o_d[kd].data(); } kd++;
+#define OI_(field, w) if (out->field) { o_i[ki].resize(b * (w)); hp.field = o_i[ki].data(); } ki++;
+        OD_(jerk_x, N) OD_(jerk_y, N) OD_(com_x, N) OD_(com_y, N) OD_(com_xd, N) OD_(com_yd, N) OD_(zmp_x, N)
+        OD_(zmp_y, N) OD_(min_margin, N) OD_(cost, 1) OD_(multipliers, as) OD_(alg_flops, 1) OD_(slacks, 2 * N)
+        OI_(status, 1) OI_(iters, 1) OI_(n_active, 1) OI_(active_idx, as)
+#undef OD_
+#undef OI_
+    }
+    Staging st(h);
+    mpcb_coupled_inputs di;
+    std::memset(&di, 0, sizeof(di));
+    mpcb_outputs dout;
+    int rc;
+    auto ptr = [](auto &v) { return v.empty() ? nullptr : v.data(); };
+    auto stage = [&]() -> int {
+        if ((rc = st.in((const double *)ptr(x0), b * 3, &di.x0)) || (rc = st.in((const double *)ptr(y0), b * 3, &di.y0)) ||
+            (rc = st.in((const double *)ptr(speed), b * 2, &di.speed)) ||
+            (rc = st.in((const double *)ptr(feet_x), b * 4, &di.feet_x)) ||
+            (rc = st.in((const double *)ptr(feet_y), b * 4, &di.feet_y)) ||
+            (rc = st.in((const int32_t *)ptr(swing0), b, &di.swing0)) ||
+            (rc = st.in((const double *)ptr(com0), b * 2, &di.com0)) ||
+            (rc = st.in((const double *)ptr(rows_pqr), b * m * 3, &di.rows_pqr)) ||
+            (rc = st.in((const double *)ptr(zref_phase), b * P * 2, &di.zref_phase)) ||
+            (rc = st.in((const double *)ptr(zref_knot), b * N * 2, &di.zref_knot)))
+            return rc;
+        return stage_outputs(st, hp, dout, b, N);
+    };
+    if ((rc = stage()) || (rc = st.commit()) || (rc = stage())) return rc;
+    // per-group views of the staged arrays
+    std::vector<mpcb_coupled_inputs> gin(gh.size());
+    std::vector<mpcb_outputs> gout(gh.size());
+    size_t first = 0;
+    for (size_t g = 0; g < gh.size(); g++) {
+        mpcb_coupled_inputs si = di;
+        mpcb_outputs so = dout;
+#define IN_(field, w) if (si.field) si.field += first * (w);
+        IN_(x0, 3) IN_(y0, 3) IN_(speed, 2) IN_(feet_x, 4) IN_(feet_y, 4) IN_(swing0, 1) IN_(com0, 2)
+        IN_(rows_pqr, m * 3) IN_(zref_phase, P * 2) IN_(zref_knot, N * 2)
+#undef IN_
+#define OUT_(field, w) if (so.field) so.field += first * (w);
+        OUT_(jerk_x, N) OUT_(jerk_y, N) OUT_(com_x, N) OUT_(com_y, N) OUT_(com_xd, N) OUT_(com_yd, N)
+        OUT_(zmp_x, N) OUT_(zmp_y, N) OUT_(min_margin, N) OUT_(cost, 1) OUT_(status, 1) OUT_(iters, 1)
+        OUT_(n_active, 1) OUT_(active_idx, as) OUT_(multipliers, as) OUT_(alg_flops, 1) OUT_(slacks, 2 * N)
+#undef OUT_
+        gin[g] = si;
+        gout[g] = so;
+        first += (size_t)gB[g];
+    }
+    if ((rc = mpcb_solve_coupled_groups(gH.data(), (int32_t)gH.size(), gB.data(), gin.data(), gout.data(),
+                                        h->own_stream)))
+        return rc;
+    if ((rc = fetch_outputs(hp, dout, b, N, h->own_stream))) return rc;
+    auto scatter = [&](auto *dst, const auto *src, size_t w) {
+        if (!dst) return;
+        for (size_t k = 0; k < b; k++) std::memcpy(dst + (size_t)perm[k] * w, src + k * w, w * sizeof(*dst));
+    };
+    scatter(out->jerk_x, hp.jerk_x, N); scatter(out->jerk_y, hp.jerk_y, N); scatter(out->com_x, hp.com_x, N);
+    scatter(out->com_y, hp.com_y, N); scatter(out->com_xd, hp.com_xd, N); scatter(out->com_yd, hp.com_yd, N);
+    scatter(out->zmp_x, hp.zmp_x, N); scatter(out->zmp_y, hp.zmp_y, N); scatter(out->min_margin, hp.min_margin, N);
+    scatter(out->cost, hp.cost, 1); scatter(out->status, hp.status, 1); scatter(out->iters, hp.iters, 1);
+    scatter(out->n_active, hp.n_active, 1); scatter(out->active_idx, hp.active_idx, as);
+    scatter(out->multipliers, hp.multipliers, as); scatter(out->alg_flops, hp.alg_flops, 1);
+    scatter(out->slacks, hp.slacks, 2 * N);
+    return count_not_ok(out->status, B);
+}
+
 int mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, const mpcb_outputs *out) {
     if (!h || !in || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
     DeviceGuard guard(h->params.device);
+    if (in->height && h->params.formulation == MPCB_COUPLED_REF && B > 0) {
+        if (int rc0 = ensure_own_stream(h)) return rc0;
+        if (!in->x0 || !in->y0 || !in->speed) return fail(MPCB_E_ARG, "missing coupled input array");
+        return solve_coupled_by_height(h, B, in, out);
+    }
+    if (int rc0 = ensure_own_stream(h)) return rc0;
     Staging st(h);
     mpcb_coupled_inputs di;
     std::memset(&di, 0, sizeof(di));
@@ -1031,6 +1344,7 @@ int mpcb_solve_box(mpcb_handle h, int32_t B, const double *x0, const double *zmi
                    const double *height, const mpcb_outputs *out) {
     if (!h || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
     DeviceGuard guard(h->params.device);
+    if (int rc0 = ensure_own_stream(h)) return rc0;
     Staging st(h);
     const double *dx0, *dmin, *dmax, *dheight;
     int rc;

@@ -1,10 +1,12 @@
-// Instance-independent tables, built once per handle on the host in long double.
+// Host side of the instance-independent tables: the layout of one QP (sizes, row bookkeeping),
+// the inputs of the device-side table construction (tables.hip), and a long-double construction
+// of the same tables on the host -- the checker of the device one (mpcb_params.table_build).
 //
 // What the reference rebuilds densely on every call -- Zx/Zu, Xvx/Xvu
 // (MPCPlanner::buildMatrix, MPCPlanner.cpp:101-156), the Hessian blocks
 // Gjerk + Gv (+ Gref) (:523-559, :723-739) and, inside the solver, the Cholesky
 // factor and J = L^-T (eiquadprog.hpp:165-176) -- depends only on
-// (N, Ts, g, height, weights, replanning window), so it is computed here once.
+// (N, Ts, g, height, weights, replanning window), so it is computed once per handle.
 #include "setup.h"
 
 #include <cmath>
@@ -123,9 +125,26 @@ std::vector<double> to_double_T(const LVec &v, int N) {
     return d;
 }
 
+// Velocity weights weightQv (MPCPlanner.cpp:535-547): constant Q, or makeGaussian(N, rw, rw) * Q * N
+// (:1161-1171, 1-based knots, integer mean and deviation).
+LVec velocity_weights(const mpcb_params &p) {
+    const int N = p.horizon;
+    LVec w(N);
+    if (p.replanning_window == 1000) {
+        for (int i = 0; i < N; i++) w[i] = p.weight_Q;
+    } else {
+        const ld mean = p.replanning_window, sd = p.replanning_window;
+        for (int i = 0; i < N; i++) {
+            const ld q = ((ld)(i + 1) - mean) / sd;
+            w[i] = expl(-0.5L * q * q) / (sqrtl(2 * (ld)M_PIl) * sd) * (ld)p.weight_Q * (ld)N;
+        }
+    }
+    return w;
+}
+
 } // namespace
 
-int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
+int build_layout(const mpcb_params &p, HostSetup &o, const char **err) {
     const int N = p.horizon;
     if (N < 1 || N > 512) {
         *err = "horizon must be in [1, 512]";
@@ -140,6 +159,10 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
         *err = "unknown formulation";
         return MPCB_E_ARG;
     }
+    if (form == MPCB_UNCONSTRAINED && !(p.weight_Q > 0)) {
+        *err = "weight_Q must be positive for UNCONSTRAINED";
+        return MPCB_E_ARG;
+    }
     const bool coupled = form == MPCB_COUPLED_JERK || form == MPCB_COUPLED_VEL || form == MPCB_COUPLED_REF;
     o = HostSetup();
     o.N = N;
@@ -149,6 +172,107 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
         *err = "weight_Qs must be positive for BOX_SLACK";
         return MPCB_E_ARG;
     }
+    if (form == MPCB_BOX_SLACK) {
+        o.slack_ls = sqrt(p.weight_Qs);
+        o.slack_g0 = 1000 * p.weight_Qs; // MPCPlanner.cpp:373
+    }
+    // Row bookkeeping.
+    o.knot_phase.assign(N, 0);
+    o.knot_row0.assign(N, 0);
+    if (coupled) {
+        const int steps = p.number_of_steps;
+        if (steps < 0 || steps > 255) {
+            *err = "number_of_steps must be in [0, 255]";
+            return MPCB_E_ARG;
+        }
+        // computeSteps (MPCPlanner.cpp:1200,1209): step_knots = floor(N/steps),
+        // phase_duration = floor(step_knots/2); per step a 4-stance then a 3-stance
+        // phase; the knots left over form a final 4-stance phase (:1309-1321).
+        // steps == 0: no footstep schedule -- every knot belongs to the trailing phase and
+        // owns four rows (4k .. 4k+3), which the caller fills (rows_pqr).
+        const int step_knots = steps > 0 ? N / steps : 0, pd = step_knots / 2;
+        const int covered = 2 * pd * steps;
+        o.steps = steps;
+        o.phase_knots = pd;
+        o.nphase = 2 * steps + 1;
+        o.m = 7 * pd * steps + 4 * (N - covered);
+        if (steps > 0 && o.m > 4 * step_knots * steps) {
+            *err = "horizon/number_of_steps leaves more trailing knots than computeSteps has rows for";
+            return MPCB_E_ARG;
+        }
+        for (int k = 0; k < N; k++) {
+            if (k < covered) {
+                const int i = k / (2 * pd), off = k % (2 * pd);
+                o.knot_phase[k] = 2 * i + (off >= pd ? 1 : 0);
+                o.knot_row0[k] = i * 7 * pd + (off < pd ? 4 * off : 4 * pd + 3 * (off - pd));
+            } else {
+                o.knot_phase[k] = 2 * steps;
+                o.knot_row0[k] = 7 * pd * steps + 4 * (k - covered);
+            }
+        }
+        o.row_knot.assign(o.m, 0);
+        o.row_slot.assign(o.m, 0);
+        for (int k = 0; k < N; k++) {
+            const int E = (o.knot_phase[k] & 1) ? 3 : 4;
+            for (int e = 0; e < E; e++) {
+                o.row_knot[o.knot_row0[k] + e] = k;
+                o.row_slot[o.knot_row0[k] + e] = e;
+            }
+        }
+    } else {
+        o.m = (form == MPCB_BOX_1D) ? 2 * N : (form == MPCB_BOX_SLACK) ? 4 * N : 0;
+        o.nphase = 0;
+        for (int k = 0; k < N; k++) o.knot_row0[k] = k;
+    }
+    return 0;
+}
+
+bool height_tables_apply(int form) {
+    return form == MPCB_BOX_1D || form == MPCB_COUPLED_JERK || form == MPCB_COUPLED_VEL;
+}
+
+void finish_scalars(const mpcb_params &p, HostSetup &o, double traceG1, double traceJ1) {
+    // traces of the full Hessian and of L^-T (eiquadprog.hpp:162,176): `axes` identical blocks
+    const ld tr = traceG1, trJ = traceJ1;
+    const int N = o.N;
+    o.traceG1 = traceG1;
+    o.c1 = (double)(tr * o.axes);
+    o.c2 = (double)(trJ * o.axes);
+    if (p.formulation == MPCB_BOX_SLACK) {
+        // G = diag(R I_N, Qs I_2N) (MPCPlanner.cpp:368-370)
+        o.c1 = (double)(tr + 2 * (ld)N * (ld)p.weight_Qs);
+        o.c2 = (double)(trJ + 2 * (ld)N / sqrtl((ld)p.weight_Qs));
+    }
+}
+
+void table_spec(const mpcb_params &p, const HostSetup &o, TableSpec &t) {
+    const int N = p.horizon, form = p.formulation;
+    t = TableSpec();
+    t.N = N;
+    t.form = form;
+    t.nphase = form == MPCB_COUPLED_REF ? o.nphase : 0;
+    t.height_tables = height_tables_apply(form);
+    t.Ts = p.Ts;
+    t.R = p.weight_R;
+    t.Qs = p.weight_Qs;
+    auto split = [](ld v, double &hi, double &lo) {
+        hi = (double)v;
+        lo = (double)(v - (ld)hi);
+    };
+    split(form == MPCB_UNCONSTRAINED ? (ld)p.weight_R / (ld)p.weight_Q : (ld)p.weight_R, t.diag_hi, t.diag_lo);
+    split((ld)p.height / (ld)p.gravity, t.c_hi, t.c_lo);
+    if (form == MPCB_COUPLED_VEL || form == MPCB_COUPLED_REF) {
+        const LVec w = velocity_weights(p);
+        t.w_hi.resize(N);
+        t.w_lo.resize(N);
+        for (int i = 0; i < N; i++) split(w[i], t.w_hi[i], t.w_lo[i]);
+    }
+    if (form == MPCB_COUPLED_REF) t.knot_phase = o.knot_phase;
+}
+
+int build_tables_host(const mpcb_params &p, HostSetup &o, const char **err) {
+    const int N = p.horizon, form = p.formulation;
+    const bool coupled = form == MPCB_COUPLED_JERK || form == MPCB_COUPLED_VEL || form == MPCB_COUPLED_REF;
 
     const ld Ts = p.Ts;
     const ld Cz[3] = {1, 0, -(ld)p.height / (ld)p.gravity};
@@ -178,17 +302,7 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
         Gm = toepT_mul(Z.col, Zx4, N, 4);
     }
     if (form == MPCB_COUPLED_VEL || form == MPCB_COUPLED_REF) {
-        // weightQv (MPCPlanner.cpp:535-547): constant Q, or Gaussian * Q * N
-        LVec w(N);
-        if (p.replanning_window == 1000) {
-            for (int i = 0; i < N; i++) w[i] = p.weight_Q;
-        } else {
-            const ld mean = p.replanning_window, sd = p.replanning_window;
-            for (int i = 0; i < N; i++) {
-                const ld q = ((ld)(i + 1) - mean) / sd;
-                w[i] = expl(-0.5L * q * q) / (sqrtl(2 * (ld)M_PIl) * sd) * (ld)p.weight_Q * (ld)N;
-            }
-        }
+        const LVec w = velocity_weights(p);
         // Xvu^T W Xvu, Xvu^T W Xvx, -Xvu^T W 1
         LVec WX((size_t)N * N, 0), WXx((size_t)N * 4, 0);
         for (int i = 0; i < N; i++) {
@@ -213,7 +327,6 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
     }
     ld tr = 0;
     for (int i = 0; i < N; i++) tr += G1[(size_t)i * N + i];
-    o.traceG1 = (double)tr;
 
     LVec L = G1;
     if (!cholesky(L, N)) {
@@ -222,15 +335,7 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
     }
     ld trJ = 0;
     for (int i = 0; i < N; i++) trJ += 1 / L[(size_t)i * N + i];
-    o.c1 = (double)(tr * o.axes);
-    o.c2 = (double)(trJ * o.axes);
-    if (form == MPCB_BOX_SLACK) {
-        // G = diag(R I_N, Qs I_2N) (MPCPlanner.cpp:368-370): traces of G and of L^-T
-        o.slack_ls = sqrt(p.weight_Qs);
-        o.slack_g0 = 1000 * p.weight_Qs; // :373
-        o.c1 = (double)(tr + 2 * (ld)N * (ld)p.weight_Qs);
-        o.c2 = (double)(trJ + 2 * (ld)N / sqrtl((ld)p.weight_Qs));
-    }
+    finish_scalars(p, o, (double)tr, (double)trJ);
 
     // W = G1^-1 Zu^T  (N x N), then the response matrices
     LVec W = ZuT;
@@ -288,86 +393,35 @@ int build_setup(const mpcb_params &p, HostSetup &o, const char **err) {
             }
         }
         o.J0 = to_double_T(J0, N); // column-major
-        LVec H((size_t)N * N, 0);
-        for (int i = 0; i < N; i++) H[(size_t)i * N + i] = -1;
-        chol_solve(L, H, N, N);
-        o.Hneg = to_double(H);
     }
 
-    // Row bookkeeping.
-    o.knot_phase.assign(N, 0);
-    o.knot_row0.assign(N, 0);
-    if (coupled) {
-        const int steps = p.number_of_steps;
-        if (steps < 0 || steps > 255) {
-            *err = "number_of_steps must be in [0, 255]";
-            return MPCB_E_ARG;
-        }
-        // computeSteps (MPCPlanner.cpp:1200,1209): step_knots = floor(N/steps),
-        // phase_duration = floor(step_knots/2); per step a 4-stance then a 3-stance
-        // phase; the knots left over form a final 4-stance phase (:1309-1321).
-        // steps == 0: no footstep schedule -- every knot belongs to the trailing phase and
-        // owns four rows (4k .. 4k+3), which the caller fills (rows_pqr).
-        const int step_knots = steps > 0 ? N / steps : 0, pd = step_knots / 2;
-        const int covered = 2 * pd * steps;
-        o.steps = steps;
-        o.phase_knots = pd;
-        o.nphase = 2 * steps + 1;
-        o.m = 7 * pd * steps + 4 * (N - covered);
-        if (steps > 0 && o.m > 4 * step_knots * steps) {
-            *err = "horizon/number_of_steps leaves more trailing knots than computeSteps has rows for";
-            return MPCB_E_ARG;
-        }
+    if (form == MPCB_COUPLED_REF) {
+        // The reference of computeCentroid is constant over a phase, so its effect is
+        // a sum over phases of (centroid of the phase) x (response summed over the
+        // phase's knots).  g0 gains -Qs Zu' zref (MPCPlanner.cpp:731-735).
+        const int P = o.nphase;
+        const ld Qs = p.weight_Qs;
+        LVec Sp((size_t)P * N, 0), Wp((size_t)P * N, 0);
+        LVec F2((size_t)4 * P, 0), F3((size_t)P * P, 0);
         for (int k = 0; k < N; k++) {
-            if (k < covered) {
-                const int i = k / (2 * pd), off = k % (2 * pd);
-                o.knot_phase[k] = 2 * i + (off >= pd ? 1 : 0);
-                o.knot_row0[k] = i * 7 * pd + (off < pd ? 4 * off : 4 * pd + 3 * (off - pd));
-            } else {
-                o.knot_phase[k] = 2 * steps;
-                o.knot_row0[k] = 7 * pd * steps + 4 * (k - covered);
+            const int ph = o.knot_phase[k];
+            for (int i = 0; i < N; i++) {
+                Sp[(size_t)ph * N + i] += Qs * S[(size_t)k * N + i];
+                Wp[(size_t)ph * N + i] += Qs * W[(size_t)i * N + k];
             }
-        }
-        o.row_knot.assign(o.m, 0);
-        o.row_slot.assign(o.m, 0);
-        for (int k = 0; k < N; k++) {
-            const int E = (o.knot_phase[k] & 1) ? 3 : 4;
-            for (int e = 0; e < E; e++) {
-                o.row_knot[o.knot_row0[k] + e] = k;
-                o.row_slot[o.knot_row0[k] + e] = e;
+            for (int a = 0; a < 4; a++) {
+                const ld zukx = Kz[(size_t)k * 4 + a] - (a < 3 ? Z.sx[(size_t)k * 3 + a] : 0);
+                F2[(size_t)a * P + ph] -= Qs * zukx;
             }
+            for (int k2 = 0; k2 < N; k2++)
+                F3[(size_t)ph * P + o.knot_phase[k2]] -= Qs * Qs * S[(size_t)k * N + k2] / 2;
         }
-        if (form == MPCB_COUPLED_REF) {
-            // The reference of computeCentroid is constant over a phase, so its effect is
-            // a sum over phases of (centroid of the phase) x (response summed over the
-            // phase's knots).  g0 gains -Qs Zu' zref (MPCPlanner.cpp:731-735).
-            const int P = o.nphase;
-            const ld Qs = p.weight_Qs;
-            LVec Sp((size_t)P * N, 0), Wp((size_t)P * N, 0);
-            LVec F2((size_t)4 * P, 0), F3((size_t)P * P, 0);
-            for (int k = 0; k < N; k++) {
-                const int ph = o.knot_phase[k];
-                for (int i = 0; i < N; i++) {
-                    Sp[(size_t)ph * N + i] += Qs * S[(size_t)k * N + i];
-                    Wp[(size_t)ph * N + i] += Qs * W[(size_t)i * N + k];
-                }
-                for (int a = 0; a < 4; a++) {
-                    const ld zukx = Kz[(size_t)k * 4 + a] - (a < 3 ? Z.sx[(size_t)k * 3 + a] : 0);
-                    F2[(size_t)a * P + ph] -= Qs * zukx;
-                }
-                for (int k2 = 0; k2 < N; k2++)
-                    F3[(size_t)ph * P + o.knot_phase[k2]] -= Qs * Qs * S[(size_t)k * N + k2] / 2;
-            }
-            o.Sp = to_double(Sp);
-            o.Wp = to_double(Wp);
-            o.F2 = to_double(F2);
-            o.F3 = to_double(F3);
-        }
-    } else {
-        o.m = (form == MPCB_BOX_1D) ? 2 * N : (form == MPCB_BOX_SLACK) ? 4 * N : 0;
-        o.nphase = 0;
-        for (int k = 0; k < N; k++) o.knot_row0[k] = k;
+        o.Sp = to_double(Sp);
+        o.Wp = to_double(Wp);
+        o.F2 = to_double(F2);
+        o.F3 = to_double(F3);
     }
+    (void)coupled;
     return 0;
 }
 
@@ -391,16 +445,7 @@ int build_height_tables(const mpcb_params &p, HostSetup &o, const char **err) {
     LVec G1((size_t)N * N, 0), Gm((size_t)N * 4, 0);
     for (int i = 0; i < N; i++) G1[(size_t)i * N + i] = p.weight_R;
     if (form == MPCB_COUPLED_VEL) {
-        LVec w(N);
-        if (p.replanning_window == 1000) {
-            for (int i = 0; i < N; i++) w[i] = p.weight_Q;
-        } else {
-            const ld mean = p.replanning_window, sd = p.replanning_window;
-            for (int i = 0; i < N; i++) {
-                const ld q = ((ld)(i + 1) - mean) / sd;
-                w[i] = expl(-0.5L * q * q) / (sqrtl(2 * (ld)M_PIl) * sd) * (ld)p.weight_Q * (ld)N;
-            }
-        }
+        const LVec w = velocity_weights(p);
         LVec WX((size_t)N * N, 0), WXx((size_t)N * 4, 0);
         for (int i = 0; i < N; i++) {
             for (int k = 0; k <= i; k++) WX[(size_t)i * N + k] = w[i] * Xv.col[i - k];

@@ -1,11 +1,12 @@
-// Host-side construction of everything that does not depend on the instance:
-// prediction matrices, the condensed Hessian block, its Cholesky factor and the
-// "response" matrices the kernels read.  Extended precision (long double) so that
-// the tables are correctly rounded doubles even when the Hessian is ill-conditioned.
+// Host side of everything that does not depend on the instance: the layout of one QP, the
+// inputs of the device-side table construction, and the long-double host construction of the
+// prediction matrices, the condensed Hessian block, its Cholesky factor and the "response"
+// matrices the kernels read (the checker of the device-side one).
 #pragma once
 #include <vector>
 
 #include "../../include/mpc_amd.h"
+#include "tables.h"
 
 namespace mpcb {
 
@@ -35,17 +36,29 @@ struct HostSetup {
     std::vector<double> zu_col, zx;           // Toeplitz first column of Zu; Zx (N x 3)
     std::vector<double> xp_col, xpx, xv_col, xvx; // the same for CoM position and velocity
     std::vector<double> J0;                   // L1^-T (N x N, column-major), upper triangular
-    std::vector<double> Hneg;                 // -G1^-1 (N x N) row-major
     // height-free tables for per-instance heights (build_height_tables); empty until asked for
     std::vector<double> Spp, Sps, Saa, Wtp, Wta;  // N x N
     std::vector<double> Kzp, Kza;                 // N x 4
 };
 
+// Validates the parameters and fills sizes and row bookkeeping (cheap, no tables).
 // Returns 0 or an MPCB_E_* code; `err` receives a message.
-int build_setup(const mpcb_params &p, HostSetup &out, const char **err);
+int build_layout(const mpcb_params &p, HostSetup &out, const char **err);
 
-// Adds the tables that let every instance of a batch have its own CoM height (box, coupled
-// jerk-only and coupled velocity formulations).  Returns 0 or an MPCB_E_* code.
+// What tables.hip builds the tables of this handle from (weights and ratios in extended precision).
+void table_spec(const mpcb_params &p, const HostSetup &layout, TableSpec &spec);
+
+// c1, c2 (traces of the full Hessian and of L^-T) from the traces of one block.
+void finish_scalars(const mpcb_params &p, HostSetup &out, double traceG1, double traceJ1);
+
+// Formulations whose Hessian does not contain Zu: one handle serves every CoM height.
+bool height_tables_apply(int formulation);
+
+// The tables in long double on the host (after build_layout).
+int build_tables_host(const mpcb_params &p, HostSetup &out, const char **err);
+
+// Host construction of the tables that let every instance of a batch have its own CoM height
+// (box, coupled jerk-only and coupled velocity formulations).  Returns 0 or an MPCB_E_* code.
 int build_height_tables(const mpcb_params &p, HostSetup &out, const char **err);
 
 } // namespace mpcb

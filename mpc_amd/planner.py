@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("MPC_AMD_LIB") or os.path.join(_HERE, "libmpc_amd.so")
 BOX_1D, COUPLED_JERK, COUPLED_VEL, COUPLED_REF, UNCONSTRAINED, BOX_SLACK = 0, 1, 2, 3, 4, 5
 OK, INFEASIBLE, ITER_CAP = 0, 1, 2
 MODE_AUTO, MODE_DENSE = 0, 1
+TABLES_DEVICE, TABLES_HOST = 0, 1
 DISPATCH_IN_ORDER, DISPATCH_LONGEST_FIRST = 0, 1
 
 # every symbol include/mpc_amd.h declares
@@ -26,7 +27,8 @@ EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constrain
            "mpcb_solve_box", "mpcb_get_matrix", "mpcb_replan_sweep_device",
            "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained", "mpcb_last_handover_count", "mpcb_last_wide_count",
            "mpcb_solve_coupled_device_noalloc", "mpcb_solve_coupled_multi", "mpcb_debug_set_stamp_buffer",
-           "mpcb_set_dispatch_hint", "mpcb_solve_coupled_multi_device", "mpcb_solve_coupled_groups")
+           "mpcb_set_dispatch_hint", "mpcb_solve_coupled_multi_device", "mpcb_solve_coupled_groups",
+           "mpcb_create_groups", "mpcb_debug_host_table")
 
 
 class Params(C.Structure):
@@ -35,7 +37,7 @@ class Params(C.Structure):
                 ("weight_Q", C.c_double), ("weight_Qs", C.c_double),
                 ("replanning_window", C.c_int32), ("number_of_steps", C.c_int32),
                 ("hip_offsets", C.c_double * 8), ("iter_cap", C.c_int32), ("device", C.c_int32),
-                ("solver_mode", C.c_int32)]
+                ("solver_mode", C.c_int32), ("table_build", C.c_int32)]
 
 
 class CoupledInputs(C.Structure):
@@ -72,6 +74,8 @@ def load_library():
         lib = C.CDLL(LIB_PATH)
         lib.mpcb_last_error.restype = C.c_char_p
         lib.mpcb_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_void_p)]
+        lib.mpcb_create_groups.argtypes = [C.POINTER(Params), C.c_int32, C.POINTER(C.c_void_p)]
+        lib.mpcb_debug_host_table.argtypes = [C.POINTER(Params), C.c_int32, C.c_void_p]
         lib.mpcb_destroy.argtypes = [C.c_void_p]
         lib.mpcb_destroy.restype = None
         lib.mpcb_num_constraints.argtypes = [C.c_void_p]
@@ -102,6 +106,21 @@ def load_library():
     return _lib
 
 
+def host_table(which, horizon, Ts=0.1, gravity=9.81, formulation=COUPLED_VEL, height=0.5, weight_R=1e-6,
+               weight_Q=1.0, weight_Qs=100.0, replanning_window=1000, number_of_steps=20):
+    """A table of the long-double host construction (mpcb_debug_host_table; needs no GPU), flat."""
+    lib = load_library()
+    p = Params()
+    p.horizon, p.formulation = int(horizon), int(formulation)
+    p.Ts, p.gravity, p.height = float(Ts), float(gravity), float(height)
+    p.weight_R, p.weight_Q, p.weight_Qs = float(weight_R), float(weight_Q), float(weight_Qs)
+    p.replanning_window, p.number_of_steps = int(replanning_window), int(number_of_steps)
+    n = _check(lib.mpcb_debug_host_table(C.byref(p), which, None))
+    out = np.zeros(n)
+    _check(lib.mpcb_debug_host_table(C.byref(p), which, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
 class MpcError(RuntimeError):
     pass
 
@@ -127,7 +146,7 @@ class BatchedPlanner:
     def __init__(self, horizon, Ts=0.1, gravity=9.81, formulation=COUPLED_VEL, height=0.5,
                  weight_R=1e-6, weight_Q=1.0, weight_Qs=100.0, replanning_window=1000,
                  number_of_steps=20, hip_offsets=None, iter_cap=0, device=0, active_stride=64,
-                 solver_mode=0):
+                 solver_mode=0, table_build=TABLES_DEVICE, _handle=None):
         import torch
         self._torch = torch
         lib = load_library()
@@ -141,15 +160,39 @@ class BatchedPlanner:
             p.hip_offsets[i] = float(hip[i])
         p.iter_cap, p.device = int(iter_cap), int(device)
         p.solver_mode = int(solver_mode)
+        p.table_build = int(table_build)
         self.params = p
         self.horizon = int(horizon)
         self.formulation = int(formulation)
         self.device = torch.device("cuda", int(device))
         self.active_stride = int(active_stride)
-        h = C.c_void_p()
-        _check(lib.mpcb_create(C.byref(p), C.byref(h)))
+        if _handle is None:
+            h = C.c_void_p()
+            _check(lib.mpcb_create(C.byref(p), C.byref(h)))
+        elif _handle == "deferred":
+            h = None    # create_groups fills it in
+        else:
+            h = _handle
         self._h = h
-        self.num_constraints = lib.mpcb_num_constraints(h)
+        self.num_constraints = lib.mpcb_num_constraints(h) if h else None
+
+    @classmethod
+    def create_groups(cls, specs, active_stride=64):
+        """One planner per entry of `specs` (dicts of constructor arguments; horizons, weights,
+        heights and formulations may all differ), their tables built together by one
+        mpcb_create_groups call -- one chain of launches for the whole list."""
+        lib = load_library()
+        pls = [cls(active_stride=active_stride, _handle="deferred", **s) for s in specs]
+        n = len(pls)
+        ps = (Params * n)()
+        for g, pl in enumerate(pls):
+            C.memmove(C.byref(ps[g]), C.byref(pl.params), C.sizeof(Params))
+        hs = (C.c_void_p * n)()
+        _check(lib.mpcb_create_groups(ps, n, hs))
+        for g, pl in enumerate(pls):
+            pl._h = C.c_void_p(hs[g])
+            pl.num_constraints = lib.mpcb_num_constraints(pl._h)
+        return pls
 
     def close(self):
         if getattr(self, "_h", None):
@@ -230,11 +273,29 @@ class BatchedPlanner:
         return _check(load_library().mpcb_last_handover_count(self._h))
 
     def matrix(self, which):
-        """Instance-independent tables (0 S, 1 W^T, 2 CoM, 3 CoM velocity: N x N;
-        4 Kz, 5 Kx: N x 4)."""
+        """Instance-independent tables copied from the device (ids of mpcb_get_matrix: 0 S, 1 W^T,
+        2 CoM, 3 CoM velocity, 4 Kz, 5 Kx, 6-11 prediction matrices, 12 L^-T, 13 F, 14-17 the
+        per-phase tables of COUPLED_REF, 18-24 the height-free parts)."""
+        lib = load_library()
+        n = _check(lib.mpcb_get_matrix(self._h, which, None))
+        out = np.zeros(n)
+        _check(lib.mpcb_get_matrix(self._h, which, out.ctypes.data_as(C.c_void_p)))
         N = self.horizon
-        out = np.zeros((N, N if which < 4 else 4))
-        _check(load_library().mpcb_get_matrix(self._h, which, out.ctypes.data_as(C.c_void_p)))
+        if n == N * N:
+            return out.reshape(N, N)
+        if which in (14, 15):
+            return out.reshape(-1, N)
+        if which == 16:
+            return out.reshape(4, -1)
+        if which == 17:
+            k = int(round(n ** 0.5))
+            return out.reshape(k, k)
+        if which == 13:
+            return out.reshape(4, 4)
+        if n == 4 * N:
+            return out.reshape(N, 4)
+        if n == 3 * N:
+            return out.reshape(N, 3)
         return out
 
     # -- solves ----------------------------------------------------------------
@@ -310,16 +371,18 @@ class BatchedPlanner:
         return res
 
     def solve_coupled_host(self, x0, y0, speed, feet_x, feet_y, swing0, com0=None,
-                           outputs=DEFAULT_OUTPUTS, out=None):
+                           outputs=DEFAULT_OUTPUTS, out=None, height=None):
         """The same call on host memory (numpy in, numpy out) through mpcb_solve_coupled: the
         library stages inputs and outputs over PCIe itself and returns when they are back.
-        out: arrays from host_output_arrays to fill (reused between calls)."""
+        out: arrays from host_output_arrays to fill (reused between calls).  height [B]: CoM height
+        per instance (COUPLED_REF: the library groups the instances by height itself)."""
         f64 = np.float64
         arrs = dict(x0=np.ascontiguousarray(x0, f64), y0=np.ascontiguousarray(y0, f64),
                     speed=np.ascontiguousarray(speed, f64), feet_x=np.ascontiguousarray(feet_x, f64),
                     feet_y=np.ascontiguousarray(feet_y, f64),
                     swing0=np.ascontiguousarray(swing0, np.int32),
-                    com0=None if com0 is None else np.ascontiguousarray(com0, f64))
+                    com0=None if com0 is None else np.ascontiguousarray(com0, f64),
+                    height=None if height is None else np.ascontiguousarray(height, f64))
         B = arrs["x0"].shape[0]
         ci = CoupledInputs()
         for k, a in arrs.items():

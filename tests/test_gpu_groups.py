@@ -96,3 +96,184 @@ def test_groups_mix_horizons_and_weights_in_one_call(P, oracle):
     other = P.BatchedPlanner(50, formulation=P.BOX_1D, weight_R=1.0)
     with pytest.raises(P.MpcError, match="coupled"):
         P.BatchedPlanner.solve_coupled_groups([pls[0], other], [prep[0], prep[1]], [outs[0], outs[1]])
+
+
+# ---- the tables themselves: built on the GPU, checked against the host construction and the
+# ---- CPU restatement's buildMatrix products
+
+_TABLE_CASES = [
+    dict(horizon=200, formulation="COUPLED_VEL", weight_R=0.01, weight_Q=1.0, number_of_steps=20),
+    dict(horizon=200, formulation="COUPLED_VEL", weight_R=1e-6, weight_Q=1.0, number_of_steps=20),
+    dict(horizon=200, formulation="COUPLED_VEL", weight_R=0.01, weight_Q=1.0, replanning_window=10, number_of_steps=20),
+    dict(horizon=200, formulation="COUPLED_REF", weight_R=0.01, weight_Q=1.0, weight_Qs=100.0, number_of_steps=20),
+    dict(horizon=150, formulation="COUPLED_REF", weight_R=0.01, weight_Q=1.0, weight_Qs=0.1, number_of_steps=10,
+         height=0.43),
+    dict(horizon=200, formulation="COUPLED_JERK", weight_R=0.01, number_of_steps=20),
+    dict(horizon=100, formulation="BOX_1D", weight_R=1.0),
+    dict(horizon=100, formulation="UNCONSTRAINED", weight_R=1e-6, weight_Q=1.0),
+    dict(horizon=64, formulation="BOX_SLACK", weight_R=0.5, weight_Qs=10.0),
+    dict(horizon=300, formulation="COUPLED_VEL", weight_R=0.01, weight_Q=1.0, number_of_steps=15),
+    dict(horizon=3, formulation="COUPLED_VEL", weight_R=0.01, weight_Q=1.0, number_of_steps=1),
+]
+_TABLE_IDS = {0: "S", 1: "Wt", 2: "Sc", 3: "Sv", 4: "Kz", 5: "Kx", 6: "zu_col", 7: "zx", 8: "xp_col", 9: "xpx",
+              10: "xv_col", 11: "xvx", 12: "J0", 13: "F", 14: "Sp", 15: "Wp", 16: "F2", 17: "F3", 18: "Spp",
+              19: "Sps", 20: "Saa", 21: "Wtp", 22: "Wta", 23: "Kzp", 24: "Kza"}
+
+
+def _spec(P, c, **more):
+    s = dict(c, **more)
+    s["formulation"] = getattr(P, s["formulation"])
+    return s
+
+
+def test_device_tables_against_the_decimal_reference(P):
+    """The tables built on the GPU against tests/golden/table_reference.npz (60-digit decimal
+    arithmetic on the model's formulas, make_table_reference.py): every entry within 4 units in the
+    last place of the table's largest entry -- i.e. correctly rounded up to the final rounding --
+    also where cond(G1) ~ 1e10 (weight_R = 1e-6, weight_Qs = 100), where the host long-double
+    construction is off by 1e-12 (tests/test_oracle.py::test_host_tables_against_the_decimal_reference)."""
+    from table_golden import golden_cases, TABLE_KEYS
+    cases = golden_cases(P)
+    pls = P.BatchedPlanner.create_groups([kw for _, kw, _ in cases])
+    worst = 0.0
+    for (name, kw, ref), pl in zip(cases, pls):
+        for key, which in TABLE_KEYS.items():
+            if key not in ref:
+                continue
+            a, b = pl.matrix(which), ref[key]
+            if key == "J0":
+                a = a.T  # column-major on the device
+            assert a.shape == b.shape, (name, key)
+            scale = np.abs(b).max()
+            err = np.abs(a - b).max() / scale if scale > 0 else np.abs(a).max()
+            worst = max(worst, err)
+            assert err <= 4 * 2.3e-16, (name, key, err)
+    print("largest difference of a GPU-built table from the decimal reference: %.2e of its largest entry" % worst)
+
+
+def test_device_tables_against_the_host_construction(P):
+    """Every table of every formulation at full size, built by ONE mpcb_create_groups call on the
+    GPU, against the long-double host construction of the same handle.  The host's 64-bit mantissa
+    limits the agreement: 1e-9 of the table's largest entry is demanded (measured: 2e-11 at
+    weight_R = 0.01, N = 200), and the prediction matrices, which involve no factorisation, must
+    agree to the last bit or two."""
+    dev = P.BatchedPlanner.create_groups([_spec(P, c) for c in _TABLE_CASES])
+    worst = {}
+    for c, pd in zip(_TABLE_CASES, dev):
+        ph = P.BatchedPlanner(**_spec(P, c, table_build=P.TABLES_HOST))
+        if pd.formulation in (P.BOX_1D, P.COUPLED_JERK, P.COUPLED_VEL):
+            # the host builds the height-free parts on first use
+            B = 2
+            if pd.formulation == P.BOX_1D:
+                bb = batches.decoupled_batch(B, N=c["horizon"])
+                ph.solve_box(bb["y0"], bb["ymin"], bb["ymax"], height=np.full(B, 0.5))
+            elif c["horizon"] >= 8:
+                ph.solve_coupled(**dict(batches.coupled_batch(B), height=np.full(B, 0.5)))
+        for which, name in _TABLE_IDS.items():
+            try:
+                a = pd.matrix(which)
+            except P.MpcError:
+                continue
+            try:
+                b = ph.matrix(which)
+            except P.MpcError:
+                continue
+            assert a.shape == b.shape, (c, name)
+            scale = np.abs(b).max()
+            err = np.abs(a - b).max() / scale if scale > 0 else np.abs(a).max()
+            worst[name] = max(worst.get(name, 0.0), err)
+            assert err <= (5e-16 if 6 <= which <= 11 else 1e-9), (c, name, err)
+        assert np.array_equal(pd.matrix(0), pd.matrix(0).T)  # S is stored exactly symmetric
+    print("largest device/host difference per table (of the table's largest entry): " +
+          " ".join("%s=%.1e" % kv for kv in sorted(worst.items())))
+
+
+def test_device_tables_vs_the_oracles_build_matrix_products(P, oracle):
+    """Independent of the library's own host construction: the prediction matrices are those of the
+    CPU restatement's buildMatrix (MPCPlanner.cpp:101-156), and the response tables satisfy their
+    defining equations with the Hessian assembled from those matrices in numpy long double
+    (MPCPlanner.cpp:523-559, 723-739): G1 W = Zu', S = Zu W, G1 Kx = -Gm, J0' G1 J0 = I."""
+    ld = np.longdouble
+    for c in (dict(N=200, form="COUPLED_VEL", R=0.01, Q=1.0, Qs=100.0, rw=1000, steps=20, h=0.5),
+              dict(N=100, form="COUPLED_VEL", R=0.01, Q=1.0, Qs=100.0, rw=10, steps=10, h=0.55),
+              dict(N=120, form="COUPLED_REF", R=0.01, Q=1.0, Qs=1.0, rw=1000, steps=12, h=0.47)):
+        N = c["N"]
+        pl = P.BatchedPlanner(N, formulation=getattr(P, c["form"]), weight_R=c["R"], weight_Q=c["Q"],
+                              weight_Qs=c["Qs"], replanning_window=c["rw"], number_of_steps=c["steps"],
+                              height=c["h"])
+        op = oracle.params(N, R=c["R"], Q=c["Q"], Qs=c["Qs"], height=c["h"])
+        Zx, Zu = oracle.build_matrix(op, 3)  # 3 = Cz, 0 = Cx, 1 = Cv
+        Xpx, Xpu = oracle.build_matrix(op, 0)
+        Xvx, Xvu = oracle.build_matrix(op, 1)
+        for which, ref in ((6, Zu[:, 0]), (7, Zx), (8, Xpu[:, 0]), (9, Xpx), (10, Xvu[:, 0]), (11, Xvx)):
+            got = pl.matrix(which)
+            assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max(), which
+        for k in range(1, N):  # Toeplitz: sub-diagonal k of the reference's matrix is constant
+            assert np.ptp(np.diagonal(Zu, -k)) <= 1e-13
+        w = np.full(N, c["Q"]) if c["rw"] == 1000 else oracle.make_gaussian(N, c["rw"], c["rw"]) * c["Q"] * N
+        G1 = c["R"] * np.eye(N, dtype=ld) + Xvu.astype(ld).T @ (w.astype(ld)[:, None] * Xvu.astype(ld))
+        Gm = np.concatenate([Xvu.astype(ld).T @ (w.astype(ld)[:, None] * Xvx.astype(ld)),
+                             -(Xvu.astype(ld).T @ w.astype(ld))[:, None]], axis=1)
+        if c["form"] == "COUPLED_REF":
+            G1 = G1 + c["Qs"] * Zu.astype(ld).T @ Zu.astype(ld)
+            Gm[:, :3] += c["Qs"] * Zu.astype(ld).T @ Zx.astype(ld)
+        W = pl.matrix(1).T.astype(ld)      # table 1 holds W^T
+        S, Kx, Kz = pl.matrix(0).astype(ld), pl.matrix(5).astype(ld), pl.matrix(4).astype(ld)
+        J0 = pl.matrix(12).T.astype(ld)    # column-major on the device
+        gn = np.abs(G1).max()
+        assert np.abs(G1 @ W - Zu.T).max() <= 1e-12 * gn * np.abs(W).max()
+        assert np.abs(Zu.astype(ld) @ W - S).max() <= 1e-13 * np.abs(S).max()
+        assert np.abs(G1 @ Kx + Gm).max() <= 1e-12 * gn * np.abs(Kx).max()
+        assert np.abs(Zu.astype(ld) @ Kx[:, :3] + Zx - Kz[:, :3]).max() <= 1e-13 * np.abs(Kz).max()
+        assert np.abs(J0.T @ G1 @ J0 - np.eye(N)).max() <= 1e-10
+        assert np.allclose(np.triu(J0), J0)
+
+
+def test_create_time_device_against_host(P):
+    """mpcb_create at N = 200 with the tables built on the GPU and on the host (reported)."""
+    import time
+    kw = dict(formulation=P.COUPLED_REF, weight_R=0.01, weight_Q=1.0, weight_Qs=100.0, number_of_steps=20)
+    P.BatchedPlanner(200, **kw)  # first use of the kernels
+    t = time.perf_counter()
+    P.BatchedPlanner(200, **kw)
+    t_dev = time.perf_counter() - t
+    t = time.perf_counter()
+    P.BatchedPlanner(200, table_build=P.TABLES_HOST, **kw)
+    t_host = time.perf_counter() - t
+    t = time.perf_counter()
+    P.BatchedPlanner.create_groups([dict(horizon=200, height=0.4 + 0.002 * k, **kw) for k in range(96)])
+    t_many = time.perf_counter() - t
+    print("mpcb_create N=200 COUPLED_REF: device %.1f ms, host %.1f ms; 96 handles in one mpcb_create_groups "
+          "call %.1f ms" % (t_dev * 1e3, t_host * 1e3, t_many * 1e3))
+    assert t_dev < t_host
+
+
+def test_zmp_reference_form_with_a_height_per_instance(P, oracle):
+    """COUPLED_REF with CoM heights ~U[0.4, 0.6] per instance through the host-pointer entry point
+    (the library groups on distinct heights: here every instance is a group of its own, plus a few
+    repeated heights) against the CPU restatement run at each instance's height."""
+    B, N, steps = 28, 200, 20
+    bt = batches.coupled_batch(B, first=52000)
+    rng = batches.SplitMix(np.arange(B), seed=99)
+    height = 0.4 + 0.2 * rng.uniform()
+    height[5] = height[17] = height[2]     # one group of three
+    height[9] = 0.5                        # the handle's own height
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_REF, weight_R=0.01, weight_Q=1.0, weight_Qs=100.0,
+                          number_of_steps=steps, height=0.5)
+    for rep in range(2):  # the second call finds every height's handle
+        o = pl.solve_coupled_host(bt["x0"], bt["y0"], bt["speed"], bt["feet_x"], bt["feet_y"], bt["swing0"],
+                                  height=height)
+    for i in range(B):
+        ref = oracle.coupled_batch(oracle.params(N, R=0.01, Q=1.0, Qs=100.0, height=float(height[i]), iter_cap=4000),
+                                   oracle.COUPLED_REF, steps, 1000, bt["x0"][i:i + 1], bt["y0"][i:i + 1],
+                                   bt["speed"][i:i + 1], bt["feet_x"][i:i + 1], bt["feet_y"][i:i + 1],
+                                   bt["swing0"][i:i + 1], nthreads=1)
+        assert o["status"][i] == ref["status"][0] and o["iters"][i] == ref["iters"][0]
+        na = ref["n_active"][0]
+        assert list(o["active_idx"][i, :na]) == list(ref["active"][0, :na])
+        for k in ("jerk_x", "jerk_y", "com_x", "com_y", "zmp_x", "zmp_y"):
+            assert _rel(o[k][i], ref[k][0]) < RTOL, (k, i)
+        assert abs(o["cost"][i] - ref["cost"][0]) <= RTOL * abs(ref["cost"][0])
+    # the device-pointer entry point cannot look at the heights: it says where to go instead
+    with pytest.raises(P.MpcError, match="mpcb_create_groups"):
+        pl.solve_coupled(**dict(bt, height=height))
