@@ -275,22 +275,19 @@ class DecoupledWorkload:
         # its longest instance of the second -- so it gets high-priority streams, and it is solved as
         # X_PARTS sub-batches with a handle and a stream each: the second stage of a sub-batch starts
         # when that sub-batch's first stage is done, not the whole axis'.
-        # (not under a process group, whose collectives bring a stream of their own into the waits:
-        # there the axis stays one batch and the step forks from the default stream, as before)
         self.parts = self.X_PARTS if split and B % self.X_PARTS == 0 and B >= 1024 else 1
         self.pl_more = [P.BatchedPlanner(self.N, formulation=P.BOX_1D, weight_R=1.0, device=dev)
                         for _ in range(self.parts - 1)]
         self.hi = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(self.parts)]
         self.side = torch.cuda.Stream(device=dev, priority=0)
         # The first sub-batch's stream is also the stream the benchmark runs on (main() makes it
-        # the current one): a step forks from it and joins back into it.  With the default stream
-        # as a fourth party of these waits, back-to-back steps stopped making progress on a GPU box
-        # with four hardware queues per process.
-        if self.parts > 1:
-            self.main_stream = self.hi[0]
-        self.ev_fork = torch.cuda.Event()
-        self.ev_join = torch.cuda.Event()
-        self.ev_join_x = [torch.cuda.Event() for _ in range(self.parts)]
+        # the current one).  The streams of a step do not wait for one another: every sub-batch's K
+        # steps are issued on its own stream and the timed region ends with a device-wide
+        # synchronisation.  (Forking from and joining into one stream around every step puts
+        # cross-queue waits on the device; on this platform's HIP runtime such a chain, issued
+        # without host synchronisation, stops for good once one of its streams shares a hardware
+        # queue with another stream of the process -- scripts/stream_forkjoin_torch_only.py.)
+        self.main_stream = self.hi[0]
         i = self.inputs
         self.px = None
         self.py = self.pl_y.prepare_box(i["y0"], i["ymin"], i["ymax"])
@@ -319,24 +316,9 @@ class DecoupledWorkload:
             self.outx_part.append(pl.output_views(self.outx, p * per, per))
 
     def step(self):
-        main = torch.cuda.current_stream()
-        self.ev_fork.record(main)
-        joins = []
         for p, pl in enumerate(self._x_planners()):
-            st = self.hi[p]
-            own = st.cuda_stream != main.cuda_stream
-            if own:
-                st.wait_event(self.ev_fork)
-            pl.solve_box_prepared(self.px[p], out=self.outx_part[p], stream=st)
-            if own:
-                self.ev_join_x[p].record(st)
-                joins.append(self.ev_join_x[p])
-        self.side.wait_event(self.ev_fork)
+            pl.solve_box_prepared(self.px[p], out=self.outx_part[p], stream=self.hi[p])
         self.pl_y.solve_box_prepared(self.py, out=self.outy, stream=self.side)
-        self.ev_join.record(self.side)
-        for e in joins:
-            main.wait_event(e)
-        main.wait_event(self.ev_join)
 
     def results(self):
         return self.outy[0]
@@ -408,6 +390,8 @@ def main():
                     help="instances timed on the host cores (0 disables, -1 = default)")
     ap.add_argument("--settle-ms", type=float, default=60.0,
                     help="untimed repetition of the step before the warm-up, for this long (0 = none)")
+    ap.add_argument("--x-split", default="auto", choices=("auto", "on", "off"),
+                    help="decoupled workload: X axis as two sub-batches on two high-priority streams (auto: on)")
     ap.add_argument("--plain", action="store_true",
                     help="warm-up and timed steps only (for profiler runs): no side measurements, no CPU baseline")
     args = ap.parse_args()
@@ -450,7 +434,8 @@ def main():
 
     if args.workload == "decoupled":
         B = args.batch or 4096
-        wl = DecoupledWorkload(B, rank * B, dev, split=not distributed)
+        split = args.x_split != "off"
+        wl = DecoupledWorkload(B, rank * B, dev, split=split)
     elif args.workload == "replanning":
         B = args.batch or 16384
         wl = ReplanningWorkload(B, rank * B, dev)

@@ -229,11 +229,15 @@ int  mpcb_solve_coupled_multi_device(const mpcb_handle *handles, int32_t n_handl
  * handles[g] (DEVICE pointers in[g], out[g]).  The reference changes horizon, weights and height
  * from one planner object or call to the next (MPCPlanner.cpp:78-98, 493-502); a batch that mixes
  * them is a list of groups, one handle per distinct parameter set (mpcb_create_groups builds the
- * handles' tables together).  The groups are enqueued back to back, spread over `stream` and two
- * library-owned streams of the device with no wait between groups -- kernels of different groups
- * overlap and fill each other's uneven ends -- and `stream` continues only after all of them
- * (one fork before the first group, one join after the last).  All handles must live on the same
- * device and be distinct.  Returns 0 or a negative error. */
+ * handles' tables together).  The groups are enqueued back to back on `stream`.  With
+ * MPCB_GROUP_LANES=2 in the environment they are spread over `stream` and two library-owned
+ * high-priority streams with no wait between groups (kernels of different groups overlap and fill
+ * each other's uneven ends: 7 % for four groups of 2,048), `stream` continuing only after all of
+ * them (one fork before the first group, one join after the last).  That is opt-in: on this
+ * platform's HIP runtime a fork/join issued call after call without a host synchronisation wedges
+ * the device queues once the calling stream shares a hardware queue with another stream, i.e. in
+ * a process with more streams than hardware queues (four per priority level by default).  All
+ * handles must live on the same device and be distinct.  Returns 0 or a negative error. */
 int  mpcb_solve_coupled_groups(const mpcb_handle *handles, int32_t n_groups, const int32_t *B,
                                const mpcb_coupled_inputs *in, const mpcb_outputs *out, void *stream);
 

@@ -62,10 +62,16 @@ constexpr size_t SCRATCH_R_OFF = SCRATCH_J_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BY
 constexpr size_t SCRATCH_BYTES = SCRATCH_R_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BYTES; // 20.0 MiB
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 constexpr int MAX_DEVICES = 64;
-// Streams and events mpcb_solve_coupled_groups spreads its groups over besides the caller's
-// stream: two per device, created on first use and kept.  Three streams with mutual waits in all
-// -- the caller's and these two -- stay within what a process' hardware queues serve without
-// two of the parties sharing a queue.
+// Streams and events mpcb_solve_coupled_groups can spread its groups over besides the caller's
+// stream (MPCB_GROUP_LANES=2 in the environment; default: every group on the caller's stream).
+// Opt-in because of a property of the HIP runtime measured on this platform: a process' streams
+// are multiplexed onto a few hardware queues per priority level (four by default), and once the
+// calling stream shares a hardware queue with any other stream, a fork/join issued call after
+// call without a host synchronisation in between -- so that the waits reach the device as
+// barrier packets on another queue's signal -- stops the queues for good.  Reproduced with
+// nothing but torch streams and sleep kernels (scripts/stream_forkjoin_torch_only.py); the same
+// chain completes when the process has no more streams than hardware queues.  The two lanes are
+// high-priority streams (another pool of hardware queues), created on first use and kept.
 constexpr int GROUP_LANES = 2;
 struct GroupLanes {
     hipStream_t stream[GROUP_LANES] = {nullptr, nullptr};
@@ -75,7 +81,6 @@ struct GroupLanes {
 static GroupLanes g_lanes[MAX_DEVICES];
 static std::mutex g_lanes_mutex;
 static unsigned char *g_scratch[MAX_DEVICES] = {nullptr};
-static bool g_scratch_clean[MAX_DEVICES] = {false}; // the scratch's counter block is known to be zero
 static std::mutex g_scratch_mutex;
 
 struct mpcb_handle_s {
@@ -418,6 +423,9 @@ static int create_finish(mpcb_handle h, const mpcb::TableSet *tables) {
     *h->count_host = 0;
     if (hipHostGetDevicePointer((void **)&h->ws.host_count, h->count_host, 0) != hipSuccess)
         return fail(MPCB_E_HIP, "hipHostGetDevicePointer failed");
+    // (diagnostic: take the handle's stream -- and with it a share of the process' hardware queues --
+    // at creation, as earlier versions of this library did, instead of at the first host-pointer call)
+    if (std::getenv("MPCB_DEBUG_EAGER_STREAM") && (rc = ensure_own_stream(h))) return rc;
     return 0;
 }
 
@@ -489,11 +497,11 @@ int mpcb_create(const mpcb_params *params, mpcb_handle *out) {
 
 namespace {
 
-// Sizes the hand-over list for a batch of B and, when the dense kernel keeps its factors in
-// HBM, its J / R slots: a small number to begin with, raised to the largest hand-over count an
-// earlier solve of this handle reported (the kernel loops over the list with as many workgroups
-// as there are slots, so fewer slots than hand-overs is slower, never wrong).  Superseded
-// buffers are freed here, after the stream has drained.
+bool first_stage_runs(mpcb_handle h) {
+    return h->params.solver_mode != MPCB_MODE_DENSE && h->params.formulation != MPCB_BOX_SLACK &&
+           h->params.formulation != MPCB_UNCONSTRAINED;
+}
+
 void release_order_buffers(mpcb_handle h) {
     if (h->order) (void)hipFree(h->order);
     if (h->order_rec) (void)hipFree(h->order_rec);
@@ -512,6 +520,11 @@ hipError_t forget_order_records(mpcb_handle h, hipStream_t stream) {
     return hipSuccess;
 }
 
+// Sizes the hand-over list for a batch of B and, when the dense kernel keeps its factors in
+// HBM, its J / R slots: a small number to begin with, raised to the largest hand-over count an
+// earlier solve of this handle reported (the kernel loops over the list with as many workgroups
+// as there are slots, so fewer slots than hand-overs is slower, never wrong).  Superseded
+// buffers are freed here, after the stream has drained.
 int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
     {
         const int seen = *static_cast<volatile int *>(h->count_host);
@@ -539,7 +552,7 @@ int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
         }
         h->list_capacity = cap;
     }
-    if (h->dispatch_hint != MPCB_DISPATCH_IN_ORDER && h->order_capacity < h->list_capacity) {
+    if (h->dispatch_hint != MPCB_DISPATCH_IN_ORDER && first_stage_runs(h) && h->order_capacity < h->list_capacity) {
         HIP_TRY(hipStreamSynchronize(stream));
         release_order_buffers(h);
         const size_t cap = (size_t)h->list_capacity;
@@ -620,7 +633,11 @@ int launch_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &o
     if (!*clean) HIP_TRY(hipMemsetAsync(ws.count, 0, mpcb::COUNTER_INTS * sizeof(int), stream));
     *clean = false;
     const int rc = enqueue_two_stage(h, di, out, B, ws, dense_grid, stream);
-    if (rc == 0) *clean = true;
+    // (a stream that is being captured records the launches without running them: then nothing
+    // is known about the counters when the next call comes)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (rc == 0 && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone)
+        *clean = true;
     return rc;
 }
 
@@ -660,11 +677,6 @@ int enqueue_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &
     }
     HIP_TRY(mpcb::launch_dense(h->ds, di, out, ws, dense_grid, stream));
     return 0;
-}
-
-bool first_stage_runs(mpcb_handle h) {
-    return h->params.solver_mode != MPCB_MODE_DENSE && h->params.formulation != MPCB_BOX_SLACK &&
-           h->params.formulation != MPCB_UNCONSTRAINED;
 }
 
 int solve_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &out, int B, hipStream_t stream) {
@@ -714,7 +726,7 @@ void mpcb_destroy(mpcb_handle h) {
 int mpcb_num_constraints(mpcb_handle h) { return h ? h->hs.m : MPCB_E_ARG; }
 int mpcb_num_phases(mpcb_handle h) { return h ? h->hs.nphase : MPCB_E_ARG; }
 
-// Diagnostic builds (-DMPCB_STAMPS): device buffer of 10 cycle counters per instance.
+// Diagnostic builds (-DMPCB_STAMPS): device buffer of 16 cycle counters per instance.
 int mpcb_debug_set_stamp_buffer(mpcb_handle h, long long *dev) {
     if (!h) return MPCB_E_ARG;
     h->ds.dbg = dev;
@@ -919,8 +931,11 @@ int mpcb_solve_coupled_device_noalloc(mpcb_handle h, int32_t B, const mpcb_coupl
     ws.J = reinterpret_cast<double *>(ptr + SCRATCH_J_OFF);
     ws.R = reinterpret_cast<double *>(ptr + SCRATCH_R_OFF);
     const int cap = h->dense_in_lds ? 512 : NOALLOC_SLOTS;
-    return launch_two_stage(h, di, *out, B, ws, B < cap ? B : cap, (hipStream_t)stream,
-                            &g_scratch_clean[h->params.device]);
+    // The scratch's counter block is cleared in front of every call (a 32-byte memset node, no
+    // allocation): under stream capture a call is only recorded, so nothing can be remembered
+    // about what an earlier call has left there, and the array is shared by every handle and thread.
+    bool clean = false;
+    return launch_two_stage(h, di, *out, B, ws, B < cap ? B : cap, (hipStream_t)stream, &clean);
 }
 
 int mpcb_solve_coupled_multi(const mpcb_handle *handles, int32_t n_handles, int32_t B,
@@ -1002,20 +1017,27 @@ int mpcb_solve_coupled_groups(const mpcb_handle *handles, int32_t n_groups, cons
     const int dev = handles[0]->params.device;
     if (dev >= MAX_DEVICES) return fail(MPCB_E_ARG, "device ordinal beyond the library's table");
     DeviceGuard guard(dev);
+    int lanes = 1; // lane 0 is the caller's stream
+    if (const char *e = std::getenv("MPCB_GROUP_LANES")) {
+        const int want = std::atoi(e);
+        lanes = 1 + (want < 0 ? 0 : want > GROUP_LANES ? GROUP_LANES : want);
+    }
+    if (lanes > n_groups) lanes = n_groups;
     GroupLanes &L = g_lanes[dev];
-    {
+    if (lanes > 1) {
         std::lock_guard<std::mutex> lock(g_lanes_mutex);
         if (!L.ready) {
+            int least = 0, greatest = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
             HIP_TRY(hipEventCreateWithFlags(&L.fork, hipEventDisableTiming));
             for (int l = 0; l < GROUP_LANES; l++) {
-                HIP_TRY(hipStreamCreateWithFlags(&L.stream[l], hipStreamNonBlocking));
+                HIP_TRY(hipStreamCreateWithPriority(&L.stream[l], hipStreamNonBlocking, greatest));
                 HIP_TRY(hipEventCreateWithFlags(&L.join[l], hipEventDisableTiming));
             }
             L.ready = true;
         }
     }
     hipStream_t s0 = (hipStream_t)stream;
-    const int lanes = n_groups < GROUP_LANES + 1 ? n_groups : GROUP_LANES + 1; // lane 0 is the caller's stream
     if (lanes > 1) {
         HIP_TRY(hipEventRecord(L.fork, s0));
         for (int l = 1; l < lanes; l++) HIP_TRY(hipStreamWaitEvent(L.stream[l - 1], L.fork, 0));

@@ -93,6 +93,20 @@ def test_groups_mix_horizons_and_weights_in_one_call(P, oracle):
             for k in ("jerk_x", "jerk_y", "com_x", "com_y", "zmp_x", "zmp_y"):
                 assert _rel(o[k][i], ref[k][i]) < RTOL, (g, k, i)
         assert (np.abs(o["cost"] - ref["cost"]) <= RTOL * np.abs(ref["cost"])).all(), g
+    # the opt-in spread over the library's two streams (one synchronised call: see the header on why
+    # it is not the default) gives the same results bit for bit
+    import os
+    plain = [_np(r) for r in res]
+    os.environ["MPCB_GROUP_LANES"] = "2"
+    try:
+        torch.cuda.synchronize()
+        res2 = P.BatchedPlanner.solve_coupled_groups(pls, prep, outs, stream=st)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["MPCB_GROUP_LANES"]
+    for g in range(len(specs)):
+        for k, v in _np(res2[g]).items():
+            assert np.array_equal(v, plain[g][k], equal_nan=True), (g, k)
     other = P.BatchedPlanner(50, formulation=P.BOX_1D, weight_R=1.0)
     with pytest.raises(P.MpcError, match="coupled"):
         P.BatchedPlanner.solve_coupled_groups([pls[0], other], [prep[0], prep[1]], [outs[0], outs[1]])

@@ -64,6 +64,30 @@ def test_no_alloc_entry_point_matches_allocating_one(P):
     _compare(P, easy, 96, 300, False)
 
 
+def test_no_alloc_entry_point_takes_no_device_memory(P):
+    """What the entry point exists for: on a handle that has never solved anything -- so that the
+    allocating path would now size its lists and 2 x 24 J / R slots of 1.28 MB -- the call leaves
+    the device's free memory where it was (the allocating call afterwards does take its slots)."""
+    import torch
+    N, steps, B = 200, 20, 24
+    fresh = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=steps,
+                             solver_mode=1)
+    prepared = fresh.prepare_coupled(**batches.coupled_batch(B, first=7000))
+    out = fresh._alloc_outputs(B, P.ALL_OUTPUTS)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    fresh.solve_coupled_prepared(prepared, out=out, no_alloc=True)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    got = {k: v.cpu().numpy().copy() for k, v in out[0].items()}
+    assert (got["status"] == 0).all()
+    fresh.solve_coupled_prepared(prepared, out=out)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] < free0 - 2 * 16 * N * N * 8  # at least the 16 initial slots of J and of R
+    for k, v in out[0].items():
+        assert np.array_equal(v.cpu().numpy(), got[k], equal_nan=True), k
+
+
 def test_no_alloc_entry_point_rejects_sizes_beyond_its_scratch(P):
     big = P.BatchedPlanner(300, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=15)
     bt = batches.coupled_batch(4)
