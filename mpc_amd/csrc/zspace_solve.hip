@@ -21,6 +21,7 @@
 // or through wave shuffles.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <type_traits>
 
@@ -272,8 +273,16 @@ __device__ __forceinline__ void drop_constraint(WaveState &W, int lane, int &iq,
 // Instances this edition cannot finish are appended to wide_list (capacity reached and a wide
 // edition follows) or to unresolved_list (for the dense kernel).  RECORD: how long the instance
 // took is noted in order_record (see dispatch_order_kernel).
+// The three argument blocks every kernel of this file starts with, in parameter order: where the
+// outputs block sits in the kernel-argument segment.
+struct LeadingArgs {
+    DevSetup sd;
+    DevIn in;
+    mpcb_outputs out;
+};
+
 template <int NPL, bool POLY, bool ROWS, bool HV, bool WIDE, bool RECORD>
-__device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out,
+__device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &in, const mpcb_outputs &,
                                                const int inst, const int lane, double *smem, int *unresolved_list,
                                                int *unresolved_count, int *warm_i, double *warm_d, int *wide_list,
                                                int *wide_count, int *order_record) {
@@ -1081,6 +1090,22 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
     int inst_e = inst;
     asm volatile("" : "+v"(lane_k), "+s"(inst_e));
     const int lane_e = lane_k;
+    // The output pointers are fetched from the kernel-argument segment here, where they are first
+    // needed: taken from the kernel's parameters they are loaded at its entry and then sit in
+    // scalar registers -- in practice in lanes of spill registers -- through the whole solve.
+    mpcb_outputs out;
+    {
+        typedef const __attribute__((address_space(4))) char *kernarg_bytes;
+        kernarg_bytes ka = (kernarg_bytes)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const __attribute__((address_space(4))) mpcb_outputs *ko =
+            (const __attribute__((address_space(4))) mpcb_outputs *)(ka + offsetof(LeadingArgs, out));
+        out.jerk_x = ko->jerk_x; out.jerk_y = ko->jerk_y; out.com_x = ko->com_x; out.com_y = ko->com_y;
+        out.com_xd = ko->com_xd; out.com_yd = ko->com_yd; out.zmp_x = ko->zmp_x; out.zmp_y = ko->zmp_y;
+        out.min_margin = ko->min_margin; out.cost = ko->cost; out.status = ko->status; out.iters = ko->iters;
+        out.n_active = ko->n_active; out.active_idx = ko->active_idx; out.multipliers = ko->multipliers;
+        out.active_stride = ko->active_stride; out.alg_flops = ko->alg_flops; out.slacks = ko->slacks;
+    }
     const bool solved = status == MPCB_OK || status == MPCB_ITER_CAP;
     if (status == STATUS_UNRESOLVED && lane_e == 0 && unresolved_list)
         unresolved_list[atomicAdd(unresolved_count, 1)] = inst_e; // re-solved by the dense kernel
