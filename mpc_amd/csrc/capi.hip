@@ -59,7 +59,11 @@ constexpr size_t SCRATCH_WIDE_OFF = SCRATCH_LIST_OFF + (size_t)NOALLOC_MAX_BATCH
 constexpr size_t SCRATCH_J_OFF = SCRATCH_WIDE_OFF + (size_t)NOALLOC_MAX_BATCH * sizeof(int);
 constexpr size_t SCRATCH_SLOT_BYTES = (size_t)NOALLOC_MAX_NVAR * NOALLOC_MAX_NVAR * sizeof(double);
 constexpr size_t SCRATCH_R_OFF = SCRATCH_J_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BYTES;
-constexpr size_t SCRATCH_BYTES = SCRATCH_R_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BYTES; // 20.0 MiB
+// hand-over records of the first stage for its wide edition, one per instance (kernels.h)
+constexpr size_t SCRATCH_WARM_I_OFF = SCRATCH_R_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BYTES;
+constexpr size_t SCRATCH_WARM_D_OFF = SCRATCH_WARM_I_OFF + (size_t)NOALLOC_MAX_BATCH * mpcb::WARM_STRIDE * sizeof(int);
+constexpr size_t SCRATCH_BYTES = SCRATCH_WARM_D_OFF + (size_t)NOALLOC_MAX_BATCH * mpcb::WARM_STRIDE * sizeof(double); // 47.0 MiB
+static_assert(SCRATCH_WARM_D_OFF % 256 == 0 && SCRATCH_WARM_I_OFF % 256 == 0, "scratch sections stay aligned");
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 constexpr int MAX_DEVICES = 64;
 // Streams and events mpcb_solve_coupled_groups can spread its groups over besides the caller's
@@ -546,7 +550,9 @@ int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
         HIP_TRY(hipMalloc((void **)&h->ws.list, (size_t)cap * sizeof(int)));
         if (h->params.formulation != MPCB_BOX_1D && h->params.formulation != MPCB_BOX_SLACK && h->wide_fits)
             HIP_TRY(hipMalloc((void **)&h->ws.wide_list, (size_t)cap * sizeof(int)));
-        if (mpcb::box_dense_applies(h->ds) && !std::getenv("MPCB_DEBUG_COLD_SECOND_STAGE")) { // hand-over records, one per instance of the batch
+        const bool coupled_wide = h->params.formulation != MPCB_BOX_1D && h->params.formulation != MPCB_BOX_SLACK &&
+                                  h->wide_fits;
+        if ((mpcb::box_dense_applies(h->ds) || coupled_wide) && !std::getenv("MPCB_DEBUG_COLD_SECOND_STAGE")) { // hand-over records, one per instance of the batch
             HIP_TRY(hipMalloc((void **)&h->ws.warm_i, (size_t)cap * mpcb::WARM_STRIDE * sizeof(int)));
             HIP_TRY(hipMalloc((void **)&h->ws.warm_d, (size_t)cap * mpcb::WARM_STRIDE * sizeof(double)));
         }
@@ -930,6 +936,8 @@ int mpcb_solve_coupled_device_noalloc(mpcb_handle h, int32_t B, const mpcb_coupl
     ws.wide_list = h->wide_fits ? reinterpret_cast<int *>(ptr + SCRATCH_WIDE_OFF) : nullptr;
     ws.J = reinterpret_cast<double *>(ptr + SCRATCH_J_OFF);
     ws.R = reinterpret_cast<double *>(ptr + SCRATCH_R_OFF);
+    ws.warm_i = h->wide_fits ? reinterpret_cast<int *>(ptr + SCRATCH_WARM_I_OFF) : nullptr;
+    ws.warm_d = h->wide_fits ? reinterpret_cast<double *>(ptr + SCRATCH_WARM_D_OFF) : nullptr;
     const int cap = h->dense_in_lds ? 512 : NOALLOC_SLOTS;
     // The scratch's counter block is cleared in front of every call (a 32-byte memset node, no
     // allocation): under stream capture a call is only recorded, so nothing can be remembered

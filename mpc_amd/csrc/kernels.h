@@ -54,11 +54,12 @@ struct DevIn {
 
 // Hand-over from the wave-per-QP kernel to the dense kernel, and the dense kernel's
 // tables and HBM workspace.
-// Record the first stage leaves for an instance it hands over (box problems with the
-// LDS-resident second stage only, else the pointers are NULL): the state at the top of the
-// outer iteration it could not finish -- working set in order, multipliers, objective and the
-// counters -- so that the second stage rebuilds its factors for that working set and carries
-// on from there instead of repeating those iterations.
+// Record the first stage leaves for an instance it hands over -- box problems: to the
+// LDS-resident dense second stage; coupled forms: to the wide edition of the wave-per-QP kernel
+// (else the pointers are NULL): the state at the top of the outer iteration it could not finish
+// -- working set in order, multipliers, objective and the counters -- so that the next stage
+// rebuilds its factors for that working set and carries on from there instead of repeating
+// those iterations.  (Coupled forms pack (knot << 2 | slot) << 12 | row into the row entries.)
 constexpr int WARM_QL = 32;       // rows a record can hold (>= the first stage's capacity)
 constexpr int WARM_STRIDE = 36;   // per instance: [0, WARM_QL) rows resp. multipliers, then
 constexpr int WARM_N = 32;        //   warm_i: number of rows, outer iterations, passes

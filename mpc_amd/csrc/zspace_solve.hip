@@ -650,6 +650,83 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
     bool zmp_current = false;   // zx, zy hold the ZMP of the final multipliers
     int ipRow = 0, ipKS = 0, ipPh = 0;
     double pip = 0.0, qip = 0.0, ucand = 0.0, s_ip = 0.0;
+    if constexpr (WIDE) {
+        // Taking over mid-solve: the first edition left the state at the top of the outer iteration
+        // it could not finish (working set in order, multipliers, objective, counters).  The factor
+        // T = R^-1 of that working set is rebuilt row by row, exactly as add_constraint appends
+        // rows (d = T'g, r = T d, new column (-r, 1) / rho), without any of the step-length logic;
+        // the solve then carries on with that iteration instead of repeating the ~32 before it.
+        const int ntop = warm_i ? ufirst(warm_i[(size_t)inst * WARM_STRIDE + WARM_N]) : 0;
+        if (ntop > 0 && ntop <= WARM_QL) {
+            const int *wi = warm_i + (size_t)inst * WARM_STRIDE;
+            const double *wd = warm_d + (size_t)inst * WARM_STRIDE;
+            if (lane < ntop) {
+                const int packed = wi[lane], row = packed & 4095, ks = packed >> 12;
+                double p, q;
+                if constexpr (ROWS) {
+                    p = rows[row * 3];
+                    q = rows[row * 3 + 1];
+                } else {
+                    const int ph = sd.knot_phase[ks >> 2];
+                    p = tab[(ph * 4 + (ks & 3)) * 3];
+                    q = tab[(ph * 4 + (ks & 3)) * 3 + 1];
+                }
+                W.wsRow[lane] = row;
+                W.wsKS[lane] = ks;
+                W.wsP[lane] = p;
+                W.wsQ[lane] = q;
+                W.wsU[lane] = wd[lane];
+            }
+            wsync();
+            const int ksv = ws_knots();
+            bool sound = true;
+            for (int a = 0; a < ntop; a++) {
+                const int ka = __builtin_amdgcn_readlane(ksv, a) >> 2;
+                const double pa = ufirst(W.wsP[a]), qa = ufirst(W.wsQ[a]);
+                const double g = lane < a ? (W.wsP[lane] * pa + W.wsQ[lane] * qa) * S_col(ksv >> 2, ka) : 0.0;
+                const double mii = ufirst((pa * pa + qa * qa) * S_col(ka, ka));
+                const int lq = lane < QL ? lane : QL - 1;
+                const double *col = W.Rinv + lq, *rowp = W.Rinv + lq * LDI;
+                double da = 0.0, ra = 0.0;
+                for (int j = 0; j < a; j += 4) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) da = fma(col[(j + q4) * LDI], lane_bcast(g, j + q4), da);
+                }
+                da = lane < a ? da : 0.0;
+                for (int k = 0; k < a; k += 4) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) ra = fma(rowp[k + q4], lane_bcast(da, k + q4), ra);
+                }
+                const double zn = ufirst(mii - wave_sum(da * da));
+                if (!(zn > 1e-7 * mii)) {
+                    sound = false;
+                    break;
+                }
+                double rho, irho;
+                sqrt_rsqrt(zn, rho, irho);
+                irho = ufirst(irho);
+                if (lane < a) W.Rinv[lane * LDI + a] = -ra * irho;
+                else if (lane == a) W.Rinv[a * LDI + a] = irho;
+                wsync();
+            }
+            if (sound) {
+                for (int a = 0; a < ntop; a++) {
+                    const int ks = __builtin_amdgcn_readlane(ksv, a);
+                    if (lane == ((ks >> 2) & 63)) actm |= 1u << (4 * ((ks >> 2) >> 6) + (ks & 3));
+                }
+                iq = ntop;
+                iters = ufirst(wi[WARM_ITERS]);
+                passes = ufirst(wi[WARM_PASSES]);
+                f = ufirst(wd[WARM_F]);
+                falg = (long long)ufirst(wd[WARM_FALG]);
+                R_norm = ufirst(wd[WARM_RNORM]);
+            } else {
+                // (not expected: the first edition factorised this very working set) start afresh
+                for (int i = lane; i < QL * LDI; i += 64) W.Rinv[i] = 0.0;
+                wsync();
+            }
+        }
+    }
     STAMP(0);
     for (;;) { // step 1 (l1)
         iters++;
@@ -1123,13 +1200,15 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
             order_record[ORDER_HEADER + inst_e] = bin;
         }
     }
-    if (status == STATUS_UNRESOLVED && warm_i) {
-        // where the dense kernel takes over: the top of this outer iteration
+    if (!WIDE && warm_i && status == (POLY ? STATUS_TO_WIDE : STATUS_UNRESOLVED)) {
+        // where the next stage takes over (box problems: the dense kernel; coupled forms: the wide
+        // edition of this kernel): the top of this outer iteration
         int *wi = warm_i + (size_t)inst_e * WARM_STRIDE;
         double *wd = warm_d + (size_t)inst_e * WARM_STRIDE;
         const int ntop = ufirst(W.topIq);
         if (lane_e < ntop) {
-            wi[lane_e] = W.oldRow[lane_e];
+            // (coupled forms: the row and its (knot, slot), 12 bits each)
+            wi[lane_e] = POLY ? (W.oldRow[lane_e] | (W.oldKS[lane_e] << 12)) : W.oldRow[lane_e];
             wd[lane_e] = W.oldU[lane_e];
         }
         if (lane_e == 0) {
@@ -1381,13 +1460,14 @@ __global__ __launch_bounds__(ORDER_THREADS) void dispatch_order_kernel(int *rec,
 template <int NPL, bool ROWS, bool HV>
 __global__ __launch_bounds__(64, 1) void zspace_wide_kernel(DevSetup sd, DevIn in, mpcb_outputs out,
                                                             const int *work_list, const int *work_count,
-                                                            int *unresolved_list, int *unresolved_count) {
+                                                            int *unresolved_list, int *unresolved_count,
+                                                            int *warm_i, double *warm_d) {
     extern __shared__ double smem[];
     const int count = ufirst(*work_count);
     for (int entry = blockIdx.x; entry < count; entry += gridDim.x) {
         solve_instance<NPL, true, ROWS, HV, true, false>(sd, in, out, ufirst(work_list[entry]),
                                                          (int)(threadIdx.x & 63), smem, unresolved_list,
-                                                         unresolved_count, nullptr, nullptr, nullptr, nullptr, nullptr);
+                                                         unresolved_count, warm_i, warm_d, nullptr, nullptr, nullptr);
         wsync();
     }
 }
@@ -1438,7 +1518,7 @@ hipError_t launch_one_wide(const DevSetup &sd, const DevIn &in, const mpcb_outpu
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64), shmem, stream, sd, in, out, ws.wide_list, ws.wide_count, ws.list,
-                       ws.count);
+                       ws.count, ws.warm_i, ws.warm_d);
     return hipGetLastError();
 }
 

@@ -434,32 +434,67 @@ def test_dense_kernel_alone_vs_oracle(P, oracle):
 
 def test_large_working_sets_wide_edition_and_dense_fallback(P, oracle):
     """weight_R = 1e-6 (the constructor default, MPCPlanner.cpp:39): working sets of 20-53 rows
-    exceed the 32 rows of the first-stage kernel, so part of the batch is taken over by its wide
-    edition (60 rows); at weight_R = 1e-8 and three times the walking speed one working set reaches
-    74 rows and goes on to the dense kernel.  The Hessian's condition number is ~1e10 and more
-    here: the reference's own double-precision Cholesky is only good to ~1e-6 relative, so the
-    tolerance is 1e-4."""
+    exceed the 32 rows of the first-stage kernel, so part of the batch is taken over mid-solve by
+    its wide edition (60 rows): every output, the jerk included, to 1e-6 of the CPU restatement,
+    identical iteration counts and working sets.  At weight_R = 1e-8 and three times the walking
+    speed one working set reaches 74 rows and goes on to the dense kernel; cond(G) ~ 1e12 there and
+    the CPU restatement's double-precision Cholesky (the reference's, eiquadprog.hpp:165) is itself
+    only good to ~1e-4, which is the tolerance of that comparison -- the GPU's own answer is held
+    to the optimality conditions instead, evaluated in extended precision."""
+    import zspace_model as Z
     N, steps = 200, 20
-    for B, R, speed_scale, beyond_wide in ((32, 1e-6, 1.0, False), (8, 1e-8, 3.0, True)):
+    for B, R, speed_scale, beyond_wide, tol in ((32, 1e-6, 1.0, False, RTOL), (8, 1e-8, 3.0, True, 1e-4)):
         bt = batches.coupled_batch(B)
         bt["speed"] = bt["speed"] * speed_scale
-        pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=R, weight_Q=1.0, number_of_steps=steps)
+        pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=R, weight_Q=1.0, number_of_steps=steps,
+                              active_stride=128)
         o = _np(pl.solve_coupled(**bt))
         ref = oracle.coupled_batch(oracle.params(N, R=R, Q=1.0, height=0.5, iter_cap=8000), oracle.COUPLED_VEL,
                                    steps, 1000, bt["x0"], bt["y0"], bt["speed"], bt["feet_x"], bt["feet_y"],
-                                   bt["swing0"], nthreads=16)
+                                   bt["swing0"], active_stride=128, nthreads=16)
         assert (o["status"] == ref["status"]).all() and (ref["n_active"] > 32).any()
         assert pl.last_wide_count() >= (ref["n_active"] > 32).sum()
         assert (pl.last_handover_count() > 0) == beyond_wide == bool((ref["n_active"] > 60).any())
         assert (o["iters"] == ref["iters"]).all()
+        assert np.allclose(o["alg_flops"], ref["falg"], rtol=1e-12)
         for i in range(B):
             na = ref["n_active"][i]
             assert o["n_active"][i] == na
-            assert list(o["active_idx"][i, :min(na, o["active_idx"].shape[1])]) == \
-                list(ref["active"][i, :min(na, o["active_idx"].shape[1])])
-            for k in ("com_x", "com_y", "zmp_x", "zmp_y"):
-                assert _rel(o[k][i], ref[k][i]) < 1e-4
-        assert (np.abs(o["cost"] - ref["cost"]) <= 1e-4 * np.abs(ref["cost"])).all()
+            assert list(o["active_idx"][i, :na]) == list(ref["active"][i, :na])
+            for k in ("com_x", "com_y", "zmp_x", "zmp_y", "jerk_x", "jerk_y"):
+                assert _rel(o[k][i], ref[k][i]) < tol, (R, k, i, _rel(o[k][i], ref[k][i]))
+        assert (np.abs(o["cost"] - ref["cost"]) <= tol * np.abs(ref["cost"])).all()
+        if beyond_wide:
+            # optimality of the instance with the largest working set, in numpy long double, from
+            # matrices assembled straight from MPCPlanner.cpp:523-605 (no factorisation involved)
+            ld = np.longdouble
+            i = int(np.argmax(o["n_active"]))
+            su = Z.Setup(N, 0.1, 9.81, 0.5, R, 1.0, 100.0, variant=1)
+            Xvu, Xvx, Zu, Zx = (a.astype(ld) for a in (su.Xvu, su.Xvx, su.Zu, su.Zx))
+            G1 = R * np.eye(N, dtype=ld) + Xvu.T @ Xvu
+            st = oracle.compute_steps(N, steps, bt["speed"][i], bt["feet_x"][i], bt["feet_y"][i], bt["swing0"][i])
+            A, b = st["A"].astype(ld), st["b"].astype(ld)
+            x = np.concatenate([o["jerk_x"][i], o["jerk_y"][i]]).astype(ld)
+            g0 = np.concatenate([Xvu.T @ (Xvx @ bt["x0"][i] - bt["speed"][i, 0]),
+                                 Xvu.T @ (Xvx @ bt["y0"][i] - bt["speed"][i, 1])])
+            Cn = np.hstack([A[:, :N] @ Zu, A[:, N:] @ Zu])
+            ci0 = b + A[:, :N] @ (Zx @ bt["x0"][i]) + A[:, N:] @ (Zx @ bt["y0"][i])
+            na = o["n_active"][i]
+            act, u = o["active_idx"][i, :na], o["multipliers"][i, :na].astype(ld)
+            Gx = np.concatenate([G1 @ x[:N], G1 @ x[N:]])
+            grad = Gx + g0 - Cn[act].T @ u
+            sres = Cn @ x + ci0
+            assert na > 60
+            assert float(np.abs(grad).max() / max(np.abs(g0).max(), np.abs(Gx).max())) < 1e-9
+            assert float(u.min()) > -1e-9 and float(np.abs(u * sres[act]).max()) < 1e-6
+            assert float(np.minimum(0, sres).sum()) > -pl_psi_threshold(G1, len(ci0))
+
+
+def pl_psi_threshold(G1, m):
+    """The reference's stopping threshold m * eps * trace(G) * trace(L^-T) * 100 (eiquadprog.hpp:267)
+    for the two-block Hessian blkdiag(G1, G1)."""
+    L = np.linalg.cholesky(G1.astype(np.float64))
+    return m * np.finfo(float).eps * 2 * float(np.trace(G1)) * 2 * float(np.sum(1.0 / np.diag(L))) * 100.0
 
 
 def test_replanning_sweep_vs_oracle(P, oracle):
