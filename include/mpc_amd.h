@@ -286,6 +286,13 @@ int  mpcb_solve_unconstrained_device(mpcb_handle h, int32_t B, const double *x0,
                                      const mpcb_outputs *out, void *stream);
 int  mpcb_solve_unconstrained(mpcb_handle h, int32_t B, const double *x0, const double *zmp_ref,
                               const mpcb_outputs *out);
+/* solveQP takes `actual_height` with every call (MPCPlanner.cpp:223-226) and its Hessian
+ * Zu'Zu + (R/Q) I depends on it: height [B] (HOST pointers throughout) gives every instance its
+ * own; the instances are grouped on distinct heights as mpcb_solve_coupled does for COUPLED_REF
+ * (tables of heights not seen before are built together on the GPU, at most 1024 are kept).
+ * height == NULL: mpcb_solve_unconstrained. */
+int  mpcb_solve_unconstrained_heights(mpcb_handle h, int32_t B, const double *x0, const double *zmp_ref,
+                                      const double *height, const mpcb_outputs *out);
 
 /* Diagnostic, no counterpart in the reference: how many instances of the handle's most recent
  * solve the first-stage kernel handed over to the dense second-stage kernel (working set

@@ -597,7 +597,7 @@ class MPCPlanner {
     // offsets are not part of the key: this class always hands the library finished polygon
     // rows, so the library never runs computeSteps with them.  At most kMaxHandles handles are
     // kept; the least recently used one is destroyed when another is needed.
-    static constexpr size_t kMaxHandles = 8;
+    static constexpr size_t kMaxHandles = 64;
     static bool height_in_tables(int formulation) {
         return formulation == MPCB_COUPLED_REF || formulation == MPCB_UNCONSTRAINED;
     }

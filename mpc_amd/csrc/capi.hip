@@ -1187,31 +1187,39 @@ int mpcb_solve_unconstrained(mpcb_handle h, int32_t B, const double *x0, const d
     return 0;
 }
 
+constexpr size_t MAX_HEIGHT_HANDLES = 1024;
+
 // COUPLED_REF with a CoM height per instance (host pointers).  The Hessian of this form contains
 // Qs Zu' Zu and Zu depends on the height (MPCPlanner.cpp:658, 728-729), so every distinct height
 // is a parameter group of its own: the instances are sorted by height, the handles of heights
 // not seen before are created together (one chain of table-building launches), the groups are
 // solved by one mpcb_solve_coupled_groups call and the results go back in the caller's order.
-constexpr size_t MAX_HEIGHT_HANDLES = 1024;
+// Instances sorted by height (`perm`: position -> instance), the distinct heights with their
+// counts, and a handle per height: the handle itself where the height is its own, else one of
+// h->by_height -- those not seen before are created here, all in one mpcb_create_groups call.
+struct HeightGroups {
+    std::vector<int> perm;
+    std::vector<double> gh;
+    std::vector<int32_t> gB;
+    std::vector<mpcb_handle> gH;
+};
 
-static int solve_coupled_by_height(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, const mpcb_outputs *out) {
-    const size_t b = (size_t)B, N = (size_t)h->hs.N, m = (size_t)h->hs.m, P = (size_t)h->hs.nphase;
-    const size_t as = out->active_stride > 0 ? (size_t)out->active_stride : 0;
+static int group_by_height(mpcb_handle h, int32_t B, const double *height, HeightGroups &G) {
+    const size_t b = (size_t)B;
     for (size_t i = 0; i < b; i++)
-        if (!(in->height[i] > 0)) return fail(MPCB_E_ARG, "height must be positive for every instance");
-    std::vector<int> perm(b);
-    std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int c) { return in->height[a] < in->height[c]; });
-    std::vector<double> gh;   // height of every group
-    std::vector<int32_t> gB;  // its size
+        if (!(height[i] > 0)) return fail(MPCB_E_ARG, "height must be positive for every instance");
+    G.perm.resize(b);
+    std::iota(G.perm.begin(), G.perm.end(), 0);
+    std::stable_sort(G.perm.begin(), G.perm.end(), [&](int a, int c) { return height[a] < height[c]; });
     for (size_t k = 0; k < b; k++) {
-        const double v = in->height[perm[k]];
-        if (gh.empty() || gh.back() != v) {
-            gh.push_back(v);
-            gB.push_back(0);
+        const double v = height[G.perm[k]];
+        if (G.gh.empty() || G.gh.back() != v) {
+            G.gh.push_back(v);
+            G.gB.push_back(0);
         }
-        gB.back()++;
+        G.gB.back()++;
     }
+    const std::vector<double> &gh = G.gh;
     if (gh.size() > MAX_HEIGHT_HANDLES)
         return fail(MPCB_E_ARG, "more than " + std::to_string(MAX_HEIGHT_HANDLES) + " distinct heights in one batch");
     auto key = [](double v) {
@@ -1249,11 +1257,23 @@ static int solve_coupled_by_height(mpcb_handle h, int32_t B, const mpcb_coupled_
         if (rc) return rc;
         for (size_t k = 0; k < fresh.size(); k++) h->by_height[key(fresh[k].height)] = made[k];
     }
-    std::vector<mpcb_handle> gH(gh.size());
+    G.gH.resize(gh.size());
     for (size_t g = 0; g < gh.size(); g++) {
-        gH[g] = gh[g] == h->params.height ? h : h->by_height[key(gh[g])];
+        G.gH[g] = gh[g] == h->params.height ? h : h->by_height[key(gh[g])];
         h->height_used[key(gh[g])] = h->height_calls;
     }
+    return 0;
+}
+
+static int solve_coupled_by_height(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, const mpcb_outputs *out) {
+    const size_t b = (size_t)B, N = (size_t)h->hs.N, m = (size_t)h->hs.m, P = (size_t)h->hs.nphase;
+    const size_t as = out->active_stride > 0 ? (size_t)out->active_stride : 0;
+    HeightGroups G;
+    if (int rc0 = group_by_height(h, B, in->height, G)) return rc0;
+    const std::vector<int> &perm = G.perm;
+    const std::vector<double> &gh = G.gh;
+    std::vector<int32_t> &gB = G.gB;
+    std::vector<mpcb_handle> &gH = G.gH;
     // inputs in group order
     auto gather = [&](const auto *src, size_t w, auto &dst) {
         if (!src) return;
@@ -1390,6 +1410,67 @@ int mpcb_solve_box(mpcb_handle h, int32_t B, const double *x0, const double *zmi
     if ((rc = mpcb_solve_box_device(h, B, dx0, dmin, dmax, dheight, &dout, h->own_stream))) return rc;
     if ((rc = fetch_outputs(*out, dout, b, N, h->own_stream))) return rc;
     return count_not_ok(out->status, B);
+}
+
+int mpcb_solve_unconstrained_heights(mpcb_handle h, int32_t B, const double *x0, const double *zmp_ref,
+                                     const double *height, const mpcb_outputs *out) {
+    if (!h || !out || B < 0) return fail(MPCB_E_ARG, "null argument or negative batch");
+    if (!height) return mpcb_solve_unconstrained(h, B, x0, zmp_ref, out);
+    if (B == 0) return 0;
+    if (!x0 || !zmp_ref) return fail(MPCB_E_ARG, "null input array");
+    if (h->params.formulation != MPCB_UNCONSTRAINED)
+        return fail(MPCB_E_ARG, "handle was not created for UNCONSTRAINED");
+    DeviceGuard guard(h->params.device);
+    if (int rc0 = ensure_own_stream(h)) return rc0;
+    const size_t b = (size_t)B, N = (size_t)h->hs.N;
+    HeightGroups G;
+    if (int rc0 = group_by_height(h, B, height, G)) return rc0;
+    // inputs in group order, outputs back in the caller's
+    std::vector<double> gx0(b * 3), gz(b * N);
+    for (size_t k = 0; k < b; k++) {
+        std::memcpy(&gx0[k * 3], x0 + (size_t)G.perm[k] * 3, 3 * sizeof(double));
+        std::memcpy(&gz[k * N], zmp_ref + (size_t)G.perm[k] * N, N * sizeof(double));
+    }
+    std::vector<double> oj, oz, oc, ov;
+    std::vector<int32_t> os;
+    mpcb_outputs hp = {};
+    if (out->jerk_x) { oj.resize(b * N); hp.jerk_x = oj.data(); }
+    if (out->zmp_x) { oz.resize(b * N); hp.zmp_x = oz.data(); }
+    if (out->com_x) { oc.resize(b * N); hp.com_x = oc.data(); }
+    if (out->com_xd) { ov.resize(b * N); hp.com_xd = ov.data(); }
+    if (out->status) { os.resize(b); hp.status = os.data(); }
+    Staging st(h);
+    const double *dx0 = nullptr, *dz = nullptr;
+    mpcb_outputs dout;
+    int rc;
+    auto stage = [&]() -> int {
+        if ((rc = st.in((const double *)gx0.data(), b * 3, &dx0)) || (rc = st.in((const double *)gz.data(), b * N, &dz)))
+            return rc;
+        return stage_outputs(st, hp, dout, b, N);
+    };
+    if ((rc = stage()) || (rc = st.commit()) || (rc = stage())) return rc;
+    size_t first = 0;
+    for (size_t g = 0; g < G.gh.size(); g++) {
+        mpcb_outputs so = dout;
+        if (so.jerk_x) so.jerk_x += first * N;
+        if (so.zmp_x) so.zmp_x += first * N;
+        if (so.com_x) so.com_x += first * N;
+        if (so.com_xd) so.com_xd += first * N;
+        if (so.status) so.status += first;
+        if ((rc = mpcb_solve_unconstrained_device(G.gH[g], G.gB[g], dx0 + first * 3, dz + first * N, &so, h->own_stream)))
+            return rc;
+        first += (size_t)G.gB[g];
+    }
+    if ((rc = fetch_outputs(hp, dout, b, N, h->own_stream))) return rc;
+    for (size_t k = 0; k < b; k++) {
+        const size_t i = (size_t)G.perm[k];
+        if (out->jerk_x) std::memcpy(out->jerk_x + i * N, &oj[k * N], N * sizeof(double));
+        if (out->zmp_x) std::memcpy(out->zmp_x + i * N, &oz[k * N], N * sizeof(double));
+        if (out->com_x) std::memcpy(out->com_x + i * N, &oc[k * N], N * sizeof(double));
+        if (out->com_xd) std::memcpy(out->com_xd + i * N, &ov[k * N], N * sizeof(double));
+        if (out->status) out->status[i] = os[k];
+    }
+    return 0;
 }
 
 } // extern "C"

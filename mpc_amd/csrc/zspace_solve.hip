@@ -806,7 +806,9 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
             W.oldRow[lane] = W.wsRow[lane];
             W.oldKS[lane] = W.wsKS[lane];
         }
-        if (warm_i && lane == 0) {
+        // (coupled forms hand over with a record only when the working set is full at a full step,
+        // and inside an outer iteration it can only shrink before that step)
+        if (warm_i && (!POLY || iq >= QL) && lane == 0) {
             W.topPasses = passes;
             W.topIq = iq;
             W.topF = f;

@@ -28,7 +28,7 @@ EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constrain
            "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained", "mpcb_last_handover_count", "mpcb_last_wide_count",
            "mpcb_solve_coupled_device_noalloc", "mpcb_solve_coupled_multi", "mpcb_debug_set_stamp_buffer",
            "mpcb_set_dispatch_hint", "mpcb_solve_coupled_multi_device", "mpcb_solve_coupled_groups",
-           "mpcb_create_groups", "mpcb_debug_host_table")
+           "mpcb_create_groups", "mpcb_debug_host_table", "mpcb_solve_unconstrained_heights")
 
 
 class Params(C.Structure):
@@ -99,6 +99,8 @@ def load_library():
         lib.mpcb_set_dispatch_hint.argtypes = [C.c_void_p, C.c_int32]
         lib.mpcb_solve_unconstrained_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                                         C.POINTER(Outputs), C.c_void_p]
+        lib.mpcb_solve_unconstrained_heights.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                         C.POINTER(Outputs)]
         lib.mpcb_replan_sweep_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                  C.POINTER(ReplanState), C.POINTER(Outputs), C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]
@@ -500,6 +502,21 @@ class BatchedPlanner:
         res, o = self._alloc_outputs(B, outputs)
         _check(load_library().mpcb_solve_unconstrained_device(self._h, B, tx.data_ptr(), tz.data_ptr(),
                                                               C.byref(o), self._stream(stream)))
+        return res
+
+    def solve_unconstrained_host(self, x0, zmp_ref, height=None, outputs=("jerk_x", "zmp_x", "com_x", "com_xd", "status")):
+        """solveQP on host memory (numpy in, numpy out) with an optional CoM height per instance
+        (mpcb_solve_unconstrained_heights: instances grouped on distinct heights by the library)."""
+        x0 = np.ascontiguousarray(x0, np.float64)
+        zr = np.ascontiguousarray(zmp_ref, np.float64)
+        B, N = x0.shape[0], self.horizon
+        hh = None if height is None else np.ascontiguousarray(height, np.float64)
+        res, o = {}, Outputs()
+        for name in outputs:
+            res[name] = np.zeros(B, np.int32) if name == "status" else np.zeros((B, N))
+            setattr(o, name, res[name].ctypes.data)
+        _check(load_library().mpcb_solve_unconstrained_heights(
+            self._h, B, x0.ctypes.data, zr.ctypes.data, None if hh is None else hh.ctypes.data, C.byref(o)))
         return res
 
     # -- receding-horizon sweep ---------------------------------------------------

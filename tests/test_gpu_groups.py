@@ -291,3 +291,29 @@ def test_zmp_reference_form_with_a_height_per_instance(P, oracle):
     # the device-pointer entry point cannot look at the heights: it says where to go instead
     with pytest.raises(P.MpcError, match="mpcb_create_groups"):
         pl.solve_coupled(**dict(bt, height=height))
+
+
+def test_unconstrained_form_with_a_height_per_instance(P, oracle):
+    """solveQP (MPCPlanner.cpp:223-237) with `actual_height` per instance: grouped on distinct
+    heights by the library, against the CPU restatement run at each height.  weight_R / weight_Q =
+    1e-6 as in the reference driver makes the jerk ill-conditioned (cond(G) ~ 1e10: jerk to 1e-3,
+    as in test_unconstrained_solve_qp), the ZMP that is being tracked agrees to 1e-6."""
+    B, N = 20, 100
+    rng = batches.SplitMix(np.arange(B), seed=5)
+    x0 = np.stack([rng.uniform(0.0, 0.2), rng.uniform(-0.1, 0.1), np.zeros(B)], axis=1)
+    zref = np.linspace(0, 0.2, N)[None, :] * (1.0 + rng.uniform(-0.3, 0.3))[:, None]
+    height = 0.4 + 0.2 * rng.uniform()
+    height[3] = height[11] = 0.5
+    pl = P.BatchedPlanner(N, formulation=P.UNCONSTRAINED, weight_R=1e-6, weight_Q=1.0, height=0.5)
+    o = pl.solve_unconstrained_host(x0, zref, height=height)
+    plain = pl.solve_unconstrained_host(x0, zref)
+    assert (o["status"] == 0).all()
+    for i in range(B):
+        p = oracle.params(N, R=1e-6, Q=1.0, height=float(height[i]))
+        jerk = oracle.solve_qp(p, x0[i], zref[i])
+        zmp = oracle.trajectory(p, 3, x0[i], jerk)
+        assert _rel(o["zmp_x"][i], zmp) < RTOL, i
+        assert _rel(o["jerk_x"][i], jerk) < 1e-3, i
+        if height[i] == 0.5:
+            assert np.array_equal(o["jerk_x"][i], plain["jerk_x"][i])
+    assert _rel(o["jerk_x"][0], plain["jerk_x"][0]) > 1e-4  # the heights matter
