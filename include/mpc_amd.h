@@ -320,7 +320,7 @@ int  mpcb_last_wide_count(mpcb_handle h);
  * gain nothing and lose nothing.  Costs (MPCB_DISPATCH_MAX_LAG + 1) B ints of device memory,
  * allocated by the next solve.  mpcb_replan_sweep_device uses the records of its own stages only
  * (stage s is ordered by stage s - k of the same call).  The _noalloc entry point always runs in
- * index order. */
+ * index order, and so do batches that bring caller-built rows (rows_pqr) or per-instance heights. */
 enum { MPCB_DISPATCH_IN_ORDER = 0, MPCB_DISPATCH_LONGEST_FIRST = 1, MPCB_DISPATCH_MAX_LAG = 8 };
 int  mpcb_set_dispatch_hint(mpcb_handle h, int32_t mode);
 

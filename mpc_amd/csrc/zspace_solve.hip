@@ -402,6 +402,15 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
         if constexpr (HV) return fma(ch2, tab_ld(tS2, uo, bo), fma(-ch, tab_ld(tS1, uo, bo), tab_ld(tS, uo, bo)));
         else return tab_ld(tS, uo, bo);
     };
+    // S[a][b] for a per-lane knot a and a wave-uniform knot b, read as S[b][a]: the table is stored
+    // exactly symmetric, and this way the lanes' reads fall into ONE row (1.6 KB at N = 200, the
+    // row the next outer iteration sweeps anyway if the candidate is added) instead of one cache
+    // line in each of up to iq rows
+    auto S_pair = [&](int lane_knot, int uniform_knot) -> double {
+        const unsigned uo = (unsigned)uniform_knot * rowB, bo = (unsigned)lane_knot * 8u;
+        if constexpr (HV) return fma(ch2, tab_ld(tS2, uo, bo), fma(-ch, tab_ld(tS1, uo, bo), tab_ld(tS, uo, bo)));
+        else return tab_ld(tS, uo, bo);
+    };
     auto Wt_row = [&](int row, unsigned byte_off) -> double {
         const unsigned ro = (unsigned)row * rowB;
         if constexpr (HV) return fma(-ch, tab_ld(tW1, ro, byte_off), tab_ld(tW, ro, byte_off));
@@ -683,7 +692,7 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
             for (int a = 0; a < ntop; a++) {
                 const int ka = __builtin_amdgcn_readlane(ksv, a) >> 2;
                 const double pa = ufirst(W.wsP[a]), qa = ufirst(W.wsQ[a]);
-                const double g = lane < a ? (W.wsP[lane] * pa + W.wsQ[lane] * qa) * S_col(ksv >> 2, ka) : 0.0;
+                const double g = lane < a ? (W.wsP[lane] * pa + W.wsQ[lane] * qa) * S_pair(ksv >> 2, ka) : 0.0;
                 const double mii = ufirst((pa * pa + qa * qa) * S_col(ka, ka));
                 const int lq = lane < QL ? lane : QL - 1;
                 const double *col = W.Rinv + lq, *rowp = W.Rinv + lq * LDI;
@@ -945,7 +954,7 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
                 if (lane < iq) {
                     if (!have_g) { // (the working set is still that of step 1: ks_top is current)
                         const int ka = ks_top >> 2;
-                        ga = (W.wsP[lane] * pip + W.wsQ[lane] * qip) * S_col(ka, kip);
+                        ga = (W.wsP[lane] * pip + W.wsQ[lane] * qip) * S_pair(ka, kip);
                     }
                     ua = W.wsU[lane];
                 }
@@ -1487,16 +1496,20 @@ hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &o
     // and wave slot are released the moment its QP is done instead of when the slowest of
     // several is (iteration counts differ by 2-3x between instances).
     const size_t shmem = wave_lds_bytes<POLY, NPL, false>(sd);
-    if (ws.order && ws.order_record) {
-        auto kfn = zspace_ordered_kernel<NPL, POLY, ROWS, HV>;
-        if (shmem > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-            if (e != hipSuccess) return e;
+    // (the ordered edition exists for the library's own footstep inputs at the handle's height;
+    // batches with caller-built rows or per-instance heights run in index order whatever the hint)
+    if constexpr (!ROWS && !HV) {
+        if (ws.order && ws.order_record) {
+            auto kfn = zspace_ordered_kernel<NPL, POLY, ROWS, HV>;
+            if (shmem > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(kfn, dim3(B), dim3(64), shmem, stream, sd, in, out, B, ws.list, ws.count, ws.warm_i,
+                               ws.warm_d, POLY ? ws.wide_list : nullptr, ws.wide_count, ws.order, ws.order_record);
+            return hipGetLastError();
         }
-        hipLaunchKernelGGL(kfn, dim3(B), dim3(64), shmem, stream, sd, in, out, B, ws.list, ws.count, ws.warm_i,
-                           ws.warm_d, POLY ? ws.wide_list : nullptr, ws.wide_count, ws.order, ws.order_record);
-        return hipGetLastError();
     }
     auto kfn = zspace_kernel<NPL, POLY, ROWS, HV>;
     if (shmem > 48 * 1024) {

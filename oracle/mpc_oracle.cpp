@@ -148,6 +148,15 @@ struct QPWork {
     double falg = 0.0;
 };
 
+/* Optional record of the decisions of one solve (diagnostics for the tests; the reference keeps
+ * nothing of the kind): one row per step-direction pass (l2a) with the quantities every branch
+ * of that pass compares.  Set by orc_solve_box_trace around a solve of the calling thread. */
+struct QPTrace {
+    int max_rows = 0, rows = 0;
+    double *rec = nullptr; /* [max_rows][ORC_TRACE_COLS] */
+};
+thread_local QPTrace *g_trace = nullptr;
+
 /* eiquadprog.hpp:450-513 */
 bool add_constraint(QPWork &w) {
     const int n = w.n;
@@ -404,6 +413,39 @@ l2a: /* :306-311  d = J^T np ; z = J2 d2 ; r = R^{-1} d1 */
     else
         t2 = kInf;
     t = std::min(t1, t2);
+    if (g_trace && g_trace->rows < g_trace->max_rows) {
+        double *rec = g_trace->rec + (size_t)g_trace->rows++ * ORC_TRACE_COLS;
+        /* runner-up of step 2's choice among the rows it may choose from, of the ratio test, and
+         * how close r comes to changing sign */
+        double s2 = kInf, t1b = kInf, rmax = 0.0, rmin_abs = kInf;
+        for (int i = 0; i < m; i++)
+            if (i != ip && w.iai[i] != -1 && w.iaexcl[i] && s[i] < s2) s2 = s[i];
+        for (int k = 0; k < iq; k++) {
+            rmax = std::max(rmax, std::fabs(r[k]));
+            rmin_abs = std::min(rmin_abs, std::fabs(r[k]));
+            if (r[k] > 0.0 && w.A[k] != l) t1b = std::min(t1b, u[k] / r[k]);
+        }
+        rec[0] = iter;
+        rec[1] = w.n_l2a;
+        rec[2] = iq;
+        rec[3] = ip;
+        rec[4] = s[ip];
+        rec[5] = s2;
+        rec[6] = t1;
+        rec[7] = t1b;
+        rec[8] = t2;
+        rec[9] = dot(z.data(), z.data(), n);
+        rec[10] = dot(z.data(), np.data(), n);
+        rec[11] = iq > 0 ? rmin_abs / std::max(rmax, 1e-300) : kInf;
+        rec[12] = l;
+        {
+            /* what add_constraint compares with eps * R_norm (:494) is |d(iq)| after its rotations,
+             * i.e. the norm of d2 */
+            double d2 = 0.0;
+            for (int j = iq; j < n; j++) d2 += d[j] * d[j];
+            rec[13] = std::sqrt(d2) / (kEps * w.R_norm);
+        }
+    }
     if (t >= kInf) { /* :350-356 */
         status = ORC_INFEASIBLE;
         f_value = kInf;
@@ -1128,6 +1170,17 @@ int orc_solve_box(const orc_params *p, const double x0[3], const double *zmin, c
     std::copy(j.begin(), j.end(), jerk);
     if (info) *info = li;
     return li.status;
+}
+
+int orc_solve_box_trace(const orc_params *p, const double x0[3], const double *zmin, const double *zmax,
+                        double *jerk, orc_info *info, int *active, int max_rows, double *rec) {
+    QPTrace tr;
+    tr.max_rows = max_rows;
+    tr.rec = rec;
+    g_trace = &tr;
+    orc_solve_box(p, x0, zmin, zmax, jerk, info, active);
+    g_trace = nullptr;
+    return tr.rows;
 }
 
 double orc_point2_is_right_of_line(const double p0[2], const double p1[2], const double p2[2]) {

@@ -81,6 +81,16 @@ int orc_solve_qp(const orc_params *p, const double x0[3], const double *zref,
 int orc_solve_box(const orc_params *p, const double x0[3], const double *zmin,
                   const double *zmax, double *jerk, orc_info *info, int *active);
 
+/* The same solve with a record of its decisions (a diagnostic of this restatement; the
+ * reference keeps nothing of the kind): one row of ORC_TRACE_COLS doubles per step-direction pass
+ * (eiquadprog.hpp:306-446) -- outer iteration, pass, working-set size, candidate row ip, s(ip),
+ * runner-up of step 2's choice, t1, runner-up of the ratio test, t2, z.z, z.n, min |r_k| / max |r_k|,
+ * blocking row, |d(iq)| / (eps R_norm).  Returns the number of rows written (<= max_rows). */
+#define ORC_TRACE_COLS 14
+int orc_solve_box_trace(const orc_params *p, const double x0[3], const double *zmin,
+                        const double *zmax, double *jerk, orc_info *info, int *active,
+                        int max_rows, double *rec /* [max_rows][ORC_TRACE_COLS] */);
+
 /* planning.h:143-149, :182-197, :236-260 */
 double orc_point2_is_right_of_line(const double p0[2], const double p1[2],
                                    const double p2[2]);

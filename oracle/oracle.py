@@ -109,6 +109,22 @@ def solve_box(p, x0, zmin, zmax):
     return jerk, info, act[:info.n_active].copy()
 
 
+TRACE_COLS = ("iter", "pass", "iq", "ip", "s_ip", "s_runner_up", "t1", "t1_runner_up", "t2", "zz", "zn",
+              "r_min_over_max", "blocking_row", "d_iq_over_eps_Rnorm")
+
+
+def solve_box_trace(p, x0, zmin, zmax, max_rows=4000):
+    """solve_box plus the record of its decisions: (jerk, info, active rows, trace [passes, 14])."""
+    x0, zmin, zmax = _d(x0), _d(zmin), _d(zmax)
+    jerk = np.zeros(p.N)
+    info = Info()
+    act = np.zeros(2 * p.N + 1, dtype=np.int32)
+    rec = np.zeros((max_rows, len(TRACE_COLS)))
+    fn = lib().orc_solve_box_trace
+    n = fn(C.byref(p), _p(x0), _p(zmin), _p(zmax), _p(jerk), C.byref(info), _p(act), max_rows, _p(rec))
+    return jerk, info, act[:info.n_active].copy(), rec[:n]
+
+
 def point2_is_right_of_line(p0, p1, p2):
     p0, p1, p2 = _d(p0), _d(p1), _d(p2)
     return lib().orc_point2_is_right_of_line(_p(p0), _p(p1), _p(p2))
