@@ -15,6 +15,8 @@
 
 #include <cstring>
 
+#include "device_common.h"
+
 // the error-free transformations below rely on every product and sum being rounded on its own
 #pragma clang fp contract(off)
 
@@ -84,7 +86,8 @@ struct TabGroup {
     dd *col;    // [4][N]     first columns of the Toeplitz matrices Zu, Xpu, Xvu, Xau
     dd *sx;     // [4][N][3]  state matrices Zx, Xpx, Xvx, Xax
     dd *w;      // [N]        velocity weights
-    dd *G;      // [N][N]     Hessian block, then (lower triangle) its Cholesky factor
+    dd *G;      // [N][N]     Hessian block, then (lower triangle) its Cholesky factor L
+    dd *Gt;     // [N][N]     L' (upper triangle): rows of it are columns of L, contiguous
     dd *Gm;     // [N][4]     g0 = Gm (pos, vel, acc, target speed)
     dd *gdiag;  // [N]        diagonal of G1
     dd *invd;   // [N]        1 / L[i][i]
@@ -192,6 +195,7 @@ __global__ void __launch_bounds__(CHOL_THREADS) cholesky_kernel(const TabGroup *
         for (int i = j + 1 + tid; i < N; i += CHOL_THREADS) {
             const dd l = dd_mul(g.G[(size_t)i * N + j], inv);
             g.G[(size_t)i * N + j] = l;
+            g.Gt[(size_t)j * N + i] = l;
             lcol[i] = l;
         }
         __syncthreads();
@@ -210,39 +214,95 @@ __global__ void __launch_bounds__(CHOL_THREADS) cholesky_kernel(const TabGroup *
     }
 }
 
-// One thread per right-hand-side column: forward and backward substitution with L.
+// Sum of a double-double over the wave (result wave-uniform): the butterfly of wave_sum with
+// double-double additions.
+__device__ __forceinline__ dd wave_sum_dd(dd v) {
+#define DD_STEP_(CTRL) v = dd_add(v, make_double2(dpp_perm_f64<CTRL>(v.x), dpp_perm_f64<CTRL>(v.y)))
+    DD_STEP_(0xB1);
+    DD_STEP_(0x4E);
+    DD_STEP_(0x141);
+    DD_STEP_(0x140);
+#undef DD_STEP_
+    v = dd_add(v, make_double2(dpp_f64<0x142, 0xA>(0.0, v.x), dpp_f64<0x142, 0xA>(0.0, v.y)));
+    v = dd_add(v, make_double2(dpp_f64<0x143, 0xC>(0.0, v.x), dpp_f64<0x143, 0xC>(0.0, v.y)));
+    return make_double2(lane63(v.x), lane63(v.y));
+}
+
+// Forward and backward substitution with L for every right-hand-side column: ONE WAVE PER COLUMN.
+// Lane l keeps the entries l, l + 64, ... of the column in registers; row i's inner product with
+// the entries already solved is a lane-parallel partial sum (a coalesced read of row i of L, or of
+// L' for the backward pass) and one wave reduction -- instead of a serial chain of i dependent
+// double-double operations in one thread.
+constexpr int SOLVE_SLOTS = 8; // horizons up to 512
 __global__ void __launch_bounds__(64) solve_kernel(const TabGroup *groups) {
     const TabGroup g = groups[blockIdx.y];
-    const int N = g.N, c = blockIdx.x * 64 + threadIdx.x;
+    const int N = g.N, c = blockIdx.x, lane = threadIdx.x;
     if (c >= g.ncol || *g.flag) return;
-    dd *X = g.X + c;
-    const size_t ld = (size_t)g.ncol;
-    bool forward = true;
-    if (c < N) { // Zu'[i][c] = zcol[c - i] for c >= i
-        const dd *z = g.col + (size_t)T_Z * N;
-        for (int i = 0; i < N; i++) X[i * ld] = c >= i ? z[c - i] : mk(0.0);
+    // what the column starts from: a column of Zu', of Gm, of the identity, of Xpu' or of Xau'
+    int kind, cc = c;
+    const dd *tcol = nullptr;
+    if (c < N) {
+        kind = 0;
+        tcol = g.col + (size_t)T_Z * N;
     } else if (c < col_J(g)) {
-        for (int i = 0; i < N; i++) X[i * ld] = g.Gm[(size_t)i * 4 + (c - N)];
-    } else if (c < col_P(g)) { // L^-T e_c: backward substitution only
-        for (int i = 0; i < N; i++) X[i * ld] = mk(i == c - col_J(g) ? 1.0 : 0.0);
-        forward = false;
+        kind = 1;
+        cc = c - N;
+    } else if (c < col_P(g)) {
+        kind = 2;
+        cc = c - col_J(g);
     } else {
+        kind = 0;
         const bool pos = c < col_A(g);
-        const int cc = c - (pos ? col_P(g) : col_A(g));
-        const dd *t = g.col + (size_t)(pos ? T_XP : T_XA) * N;
-        for (int i = 0; i < N; i++) X[i * ld] = cc >= i ? t[cc - i] : mk(0.0);
+        cc = c - (pos ? col_P(g) : col_A(g));
+        tcol = g.col + (size_t)(pos ? T_XP : T_XA) * N;
     }
-    if (forward)
+    auto rhs = [&](int i) -> dd { // entry i of the right-hand side (any lane may ask for any entry)
+        if (kind == 0) return cc >= i ? tcol[cc - i] : mk(0.0); // T'[i][cc] = tcol[cc - i] for cc >= i
+        if (kind == 1) return g.Gm[(size_t)i * 4 + cc];
+        return mk(i == cc ? 1.0 : 0.0);
+    };
+    dd xs[SOLVE_SLOTS];
+#pragma unroll
+    for (int j = 0; j < SOLVE_SLOTS; j++) {
+        const int k = lane + 64 * j;
+        xs[j] = k < N ? rhs(k) : mk(0.0);
+    }
+    if (kind != 2) { // (L^-T e_c needs the backward pass only)
         for (int i = 0; i < N; i++) {
-            dd s = X[i * ld];
             const dd *Li = g.G + (size_t)i * N;
-            for (int k = 0; k < i; k++) s = dd_sub(s, dd_mul(Li[k], X[k * ld]));
-            X[i * ld] = dd_mul(s, g.invd[i]);
+            dd part = mk(0.0);
+#pragma unroll
+            for (int j = 0; j < SOLVE_SLOTS; j++) {
+                const int k = lane + 64 * j;
+                if (64 * j < i && k < i) part = dd_add(part, dd_mul(Li[k], xs[j]));
+            }
+            const dd tot = wave_sum_dd(part);
+            const dd xi = dd_mul(dd_sub(rhs(i), tot), g.invd[i]);
+#pragma unroll
+            for (int j = 0; j < SOLVE_SLOTS; j++)
+                if (lane + 64 * j == i) xs[j] = xi;
         }
+    }
     for (int i = N - 1; i >= 0; i--) {
-        dd s = X[i * ld];
-        for (int k = i + 1; k < N; k++) s = dd_sub(s, dd_mul(g.G[(size_t)k * N + i], X[k * ld]));
-        X[i * ld] = dd_mul(s, g.invd[i]);
+        const dd *Lti = g.Gt + (size_t)i * N; // L[k][i], k > i
+        dd part = mk(0.0), yi = mk(0.0);
+#pragma unroll
+        for (int j = 0; j < SOLVE_SLOTS; j++) {
+            const int k = lane + 64 * j;
+            if (64 * j + 63 > i && k > i && k < N) part = dd_add(part, dd_mul(Lti[k], xs[j]));
+            if (k == i) yi = xs[j];
+        }
+        // (the entry being solved for sits in one lane: it joins the sum with the opposite sign)
+        const dd tot = wave_sum_dd(dd_sub(yi, part));
+        const dd xi = dd_mul(tot, g.invd[i]);
+#pragma unroll
+        for (int j = 0; j < SOLVE_SLOTS; j++)
+            if (lane + 64 * j == i) xs[j] = xi;
+    }
+#pragma unroll
+    for (int j = 0; j < SOLVE_SLOTS; j++) {
+        const int k = lane + 64 * j;
+        if (k < N) g.X[(size_t)k * g.ncol + c] = xs[j];
     }
 }
 
@@ -419,6 +479,7 @@ void carve(const TableSpec &s, TabGroup &g, Carver &ws, Carver &out) {
     g.sx = ws.take<dd>(4 * N * 3);
     g.w = ws.take<dd>(N);
     g.G = ws.take<dd>(N * N);
+    g.Gt = ws.take<dd>(N * N);
     g.Gm = ws.take<dd>(N * 4);
     g.gdiag = ws.take<dd>(N);
     g.invd = ws.take<dd>(N);
@@ -537,7 +598,7 @@ int build_tables_device(const TableSpec *specs, int n, TableSet *out, hipStream_
         hipLaunchKernelGGL(predict_kernel, dim3((maxN + 63) / 64, un), dim3(64), 0, stream, groups_dev);
         hipLaunchKernelGGL(hessian_kernel, dim3(maxN, un), dim3(256), 0, stream, groups_dev);
         hipLaunchKernelGGL(cholesky_kernel, dim3(un), dim3(CHOL_THREADS), sizeof(dd) * (size_t)maxN, stream, groups_dev);
-        hipLaunchKernelGGL(solve_kernel, dim3((maxcol + 63) / 64, un), dim3(64), 0, stream, groups_dev);
+        hipLaunchKernelGGL(solve_kernel, dim3(maxcol, un), dim3(64), 0, stream, groups_dev);
         hipLaunchKernelGGL(product_kernel, dim3(maxN, un), dim3(256), 0, stream, groups_dev);
         hipLaunchKernelGGL(square_tables_kernel, dim3(maxN, un), dim3(256), 0, stream, groups_dev);
         hipLaunchKernelGGL(small_tables_kernel, dim3(un), dim3(256), 0, stream, groups_dev);

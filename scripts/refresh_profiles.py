@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""After scripts/profile_all.sh: writes the committed summaries of gpurun_out/r2_prof_* into a
+"""After scripts/profile_all.sh: writes the committed summaries of gpurun_out/<prefix>* into a
 profiles/ directory (counter summaries, rocprofv3's kernel statistics, the decoupled workload's
 two-queue timeline, compiler-reported resource usage of every kernel).
 
-    python scripts/refresh_profiles.py profiles/r02 [workload,workload...] [--resources]
+    python scripts/refresh_profiles.py profiles/r03 [workload,workload...] [--resources] [--prefix=r3_prof_]
 """
 import csv
 import glob
@@ -58,15 +58,16 @@ def resource_usage(dst):
 
 def main():
     dst = sys.argv[1]
+    prefix = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--prefix=")), "r3_prof_")
     os.makedirs(dst, exist_ok=True)
     for wl in (sys.argv[2].split(",") if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else WORKLOADS):
-        src = os.path.join(ROOT, "gpurun_out", "r2_prof_" + wl)
+        src = os.path.join(ROOT, "gpurun_out", prefix + wl)
         subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "summarize_profile.py"), src,
                                os.path.join(dst, wl + "_summary.json")])
         stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
         open(os.path.join(dst, wl + "_kernel_stats.csv"), "w").write(open(stats).read())
-    if os.path.isdir(os.path.join(ROOT, "gpurun_out", "r2_prof_decoupled")):
-        timeline(os.path.join(ROOT, "gpurun_out", "r2_prof_decoupled"), os.path.join(dst, "decoupled_timeline.txt"))
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out", prefix + "decoupled")):
+        timeline(os.path.join(ROOT, "gpurun_out", prefix + "decoupled"), os.path.join(dst, "decoupled_timeline.txt"))
     if "--resources" in sys.argv:
         resource_usage(os.path.join(dst, "kernel_resource_usage.txt"))
 
