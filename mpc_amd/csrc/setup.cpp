@@ -253,7 +253,6 @@ void table_spec(const mpcb_params &p, const HostSetup &o, TableSpec &t) {
     t.nphase = form == MPCB_COUPLED_REF ? o.nphase : 0;
     t.height_tables = height_tables_apply(form);
     t.Ts = p.Ts;
-    t.R = p.weight_R;
     t.Qs = p.weight_Qs;
     auto split = [](ld v, double &hi, double &lo) {
         hi = (double)v;
@@ -272,7 +271,6 @@ void table_spec(const mpcb_params &p, const HostSetup &o, TableSpec &t) {
 
 int build_tables_host(const mpcb_params &p, HostSetup &o, const char **err) {
     const int N = p.horizon, form = p.formulation;
-    const bool coupled = form == MPCB_COUPLED_JERK || form == MPCB_COUPLED_VEL || form == MPCB_COUPLED_REF;
 
     const ld Ts = p.Ts;
     const ld Cz[3] = {1, 0, -(ld)p.height / (ld)p.gravity};
@@ -421,7 +419,6 @@ int build_tables_host(const mpcb_params &p, HostSetup &o, const char **err) {
         o.F2 = to_double(F2);
         o.F3 = to_double(F3);
     }
-    (void)coupled;
     return 0;
 }
 

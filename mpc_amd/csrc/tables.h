@@ -19,7 +19,7 @@ namespace mpcb {
 struct TableSpec {
     int N = 0, form = 0, nphase = 0;
     bool height_tables = false;        // also build the height-free parts (per-instance heights)
-    double Ts = 0, R = 0, Qs = 0;
+    double Ts = 0, Qs = 0;
     double diag_hi = 0, diag_lo = 0;   // diagonal term of G1: R, or R/Q for solveQP
     double c_hi = 0, c_lo = 0;         // height / gravity
     std::vector<double> w_hi, w_lo;    // [N] velocity weights (empty: no velocity term)
