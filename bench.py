@@ -264,8 +264,10 @@ class ReplanningWorkload:
 class DecoupledWorkload:
     unit = "solves/s"
 
-    def __init__(self, B, first, dev, split=True):
+    def __init__(self, B, first, dev, split=True, parts=0):
         self.N = 100
+        if parts:
+            self.X_PARTS = parts
         self.B = B
         self.name = "decoupled"
         self.inputs = batches.decoupled_batch(B, N=self.N, steps=10, first=first)
@@ -297,6 +299,9 @@ class DecoupledWorkload:
         self.outx = self.pl._alloc_outputs(B, P.ALL_OUTPUTS)
         self.outy = self.pl._alloc_outputs(B, P.ALL_OUTPUTS)
         self._prepare_x()
+        # three free-running streams: no one stream's events bracket "the dominant kernel's launches",
+        # so its duration is taken from the committed kernel trace of the same sources
+        self.kernel_time_from_profile = True
         self.units = B  # one unit = one X/Y pair (two scalar QPs)
         self.launches = self.parts + 1  # second-stage launches per step: the X sub-batches' and the Y axis'
         self.alg_bytes = 2 * B * (8 * (3 + 2 * self.N + 2 * self.N + 1) + 4 * (self.pl.active_stride + 4))
@@ -395,6 +400,7 @@ def main():
                     help="untimed repetition of the step before the warm-up, for this long (0 = none)")
     ap.add_argument("--x-split", default="auto", choices=("auto", "on", "off"),
                     help="decoupled workload: X axis as two sub-batches on two high-priority streams (auto: on)")
+    ap.add_argument("--x-parts", type=int, default=0, help="decoupled workload: number of X sub-batches (0 = default)")
     ap.add_argument("--plain", action="store_true",
                     help="warm-up and timed steps only (for profiler runs): no side measurements, no CPU baseline")
     args = ap.parse_args()
@@ -438,7 +444,7 @@ def main():
     if args.workload == "decoupled":
         B = args.batch or 4096
         split = args.x_split != "off"
-        wl = DecoupledWorkload(B, rank * B, dev, split=split)
+        wl = DecoupledWorkload(B, rank * B, dev, split=split, parts=args.x_parts)
     elif args.workload == "replanning":
         B = args.batch or 16384
         wl = ReplanningWorkload(B, rank * B, dev)
@@ -647,7 +653,17 @@ def main():
             ex = prof.get("executed_f64_flops_per_launch")
             # the counters belong to the profiled batch; scale to this run's units
             scale = wl.units / wl.launches / max(1.0, float(prof.get("units_per_launch") or wl.units / wl.launches))
-            if ex:
+            if ex and getattr(wl, "kernel_time_from_profile", False) and r["profiled_kernel_avg_ms"]:
+                # (its launches run on several free-running streams: no event pair of this run times them)
+                r["kernel_ms"] = r["profiled_kernel_avg_ms"]
+                r["executed_f64_gflop_per_launch"] = ex / 1e9
+                r["achieved"] = ex / (r["profiled_kernel_avg_ms"] / 1e3) / 1e12
+                r["frac"] = r["achieved"] / peak_tf
+                r["note"] = ("achieved = fp64 operations the dominant kernel issued per launch (SQ_INSTS_VALU_{FMA,ADD,"
+                             "MUL}_F64 x 64 lanes, FMA = 2) / its average launch duration, both from the rocprofv3 passes "
+                             "of the same kernel sources (profile_source): the step runs on three streams that do not "
+                             "wait for one another, so no event pair of this run brackets that kernel's launches")
+            elif ex:
                 r["executed_f64_gflop_per_launch"] = ex * scale / 1e9
                 r["achieved"] = ex * scale / kernel_s / 1e12
                 r["frac"] = r["achieved"] / peak_tf
