@@ -281,7 +281,8 @@ int  mpcb_solve_box(mpcb_handle h, int32_t B, const double *x0, const double *zm
                     const double *zmax, const double *height, const mpcb_outputs *out);
 
 /* Unconstrained ZMP tracking: solveQP (MPCPlanner.cpp:223-237) for B instances.
- * x0 [B][3], zmp_ref [B][N].  Outputs: jerk_x, zmp_x, com_x, com_xd (status = OK). */
+ * x0 [B][3], zmp_ref [B][N].  Outputs: jerk_x, zmp_x, com_x, com_xd (status = OK, iters = 0,
+ * n_active = 0 where asked for; no other output is written). */
 int  mpcb_solve_unconstrained_device(mpcb_handle h, int32_t B, const double *x0, const double *zmp_ref,
                                      const mpcb_outputs *out, void *stream);
 int  mpcb_solve_unconstrained(mpcb_handle h, int32_t B, const double *x0, const double *zmp_ref,

@@ -293,6 +293,17 @@ void worker_stop(mpcb_handle h) {
     h->worker = nullptr;
 }
 
+// Waits for the stream when the scope is left early: copies queued into (or out of) host
+// vectors of the enclosing function must not outlive them on an error path.
+struct DrainOnExit {
+    hipStream_t stream;
+    bool armed = true;
+    explicit DrainOnExit(hipStream_t s) : stream(s) {}
+    ~DrainOnExit() {
+        if (armed) (void)hipStreamSynchronize(stream);
+    }
+};
+
 int count_not_ok(const int32_t *status, int B) {
     int n = 0;
     if (status)
@@ -325,10 +336,10 @@ static int create_begin(const mpcb_params *params, mpcb_handle *out) {
     return 0;
 }
 
-// Points the kernels' argument blocks at tables built on the device.
+// Points the kernels' argument blocks at tables built on the device (the handle already owns
+// the allocation they live in).
 static void adopt_tables(mpcb_handle h, const mpcb::TableSet &t) {
     mpcb::DevSetup &ds = h->ds;
-    h->dev_allocs.push_back(t.block);
     ds.S = t.S; ds.Wt = t.Wt; ds.Sc = t.Sc; ds.Sv = t.Sv;
     ds.Kx = t.Kx; ds.Kz = t.Kz; ds.Kc = t.Kc; ds.Kv = t.Kv;
     ds.Sp = t.Sp; ds.Wp = t.Wp; ds.F2 = t.F2; ds.F3 = t.F3;
@@ -480,17 +491,14 @@ int mpcb_create_groups(const mpcb_params *params, int32_t n, mpcb_handle *out) {
             return undo(rc);
         }
     }
+    // every set's allocation belongs to its handle from here on (mpcb_destroy frees it)
     std::vector<const mpcb::TableSet *> mine(n, nullptr);
-    for (size_t k = 0; k < which.size(); k++) mine[which[k]] = &sets[k];
+    for (size_t k = 0; k < which.size(); k++) {
+        mine[which[k]] = &sets[k];
+        out[which[k]]->dev_allocs.push_back(sets[k].block);
+    }
     for (int q = 0; q < n; q++)
-        if ((rc = create_finish(out[q], mine[q]))) {
-            // tables not yet adopted by a handle are still ours to free
-            for (int r = q; r < n; r++)
-                if (mine[r] && mine[r]->block &&
-                    (r > q || out[q]->dev_allocs.empty() || out[q]->dev_allocs.front() != mine[r]->block))
-                    (void)hipFree(mine[r]->block);
-            return undo(rc);
-        }
+        if ((rc = create_finish(out[q], mine[q]))) return undo(rc);
     return 0;
 }
 
@@ -1035,12 +1043,13 @@ int mpcb_solve_coupled_groups(const mpcb_handle *handles, int32_t n_groups, cons
     if (lanes > 1) {
         std::lock_guard<std::mutex> lock(g_lanes_mutex);
         if (!L.ready) {
+            // (what an earlier, failed attempt created is kept and used: nothing is made twice)
             int least = 0, greatest = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIP_TRY(hipEventCreateWithFlags(&L.fork, hipEventDisableTiming));
+            if (!L.fork) HIP_TRY(hipEventCreateWithFlags(&L.fork, hipEventDisableTiming));
             for (int l = 0; l < GROUP_LANES; l++) {
-                HIP_TRY(hipStreamCreateWithPriority(&L.stream[l], hipStreamNonBlocking, greatest));
-                HIP_TRY(hipEventCreateWithFlags(&L.join[l], hipEventDisableTiming));
+                if (!L.stream[l]) HIP_TRY(hipStreamCreateWithPriority(&L.stream[l], hipStreamNonBlocking, greatest));
+                if (!L.join[l]) HIP_TRY(hipEventCreateWithFlags(&L.join[l], hipEventDisableTiming));
             }
             L.ready = true;
         }
@@ -1301,6 +1310,7 @@ static int solve_coupled_by_height(mpcb_handle h, int32_t B, const mpcb_coupled_
 #undef OI_
     }
     Staging st(h);
+    DrainOnExit drain(h->own_stream);
     mpcb_coupled_inputs di;
     std::memset(&di, 0, sizeof(di));
     mpcb_outputs dout;
@@ -1344,6 +1354,7 @@ static int solve_coupled_by_height(mpcb_handle h, int32_t B, const mpcb_coupled_
                                         h->own_stream)))
         return rc;
     if ((rc = fetch_outputs(hp, dout, b, N, h->own_stream))) return rc;
+    drain.armed = false; // (fetch_outputs has waited)
     auto scatter = [&](auto *dst, const auto *src, size_t w) {
         if (!dst) return;
         for (size_t k = 0; k < b; k++) std::memcpy(dst + (size_t)perm[k] * w, src + k * w, w * sizeof(*dst));
@@ -1431,6 +1442,7 @@ int mpcb_solve_unconstrained_heights(mpcb_handle h, int32_t B, const double *x0,
         std::memcpy(&gx0[k * 3], x0 + (size_t)G.perm[k] * 3, 3 * sizeof(double));
         std::memcpy(&gz[k * N], zmp_ref + (size_t)G.perm[k] * N, N * sizeof(double));
     }
+    // (everything solveQP produces: the kernel writes these outputs and no others)
     std::vector<double> oj, oz, oc, ov;
     std::vector<int32_t> os;
     mpcb_outputs hp = {};
@@ -1439,7 +1451,10 @@ int mpcb_solve_unconstrained_heights(mpcb_handle h, int32_t B, const double *x0,
     if (out->com_x) { oc.resize(b * N); hp.com_x = oc.data(); }
     if (out->com_xd) { ov.resize(b * N); hp.com_xd = ov.data(); }
     if (out->status) { os.resize(b); hp.status = os.data(); }
+    if (out->iters) std::fill(out->iters, out->iters + b, 0);       // (no iterations, empty working set:
+    if (out->n_active) std::fill(out->n_active, out->n_active + b, 0); //  what the kernel reports for solveQP)
     Staging st(h);
+    DrainOnExit drain(h->own_stream);
     const double *dx0 = nullptr, *dz = nullptr;
     mpcb_outputs dout;
     int rc;
@@ -1462,6 +1477,7 @@ int mpcb_solve_unconstrained_heights(mpcb_handle h, int32_t B, const double *x0,
         first += (size_t)G.gB[g];
     }
     if ((rc = fetch_outputs(hp, dout, b, N, h->own_stream))) return rc;
+    drain.armed = false; // (fetch_outputs has waited)
     for (size_t k = 0; k < b; k++) {
         const size_t i = (size_t)G.perm[k];
         if (out->jerk_x) std::memcpy(out->jerk_x + i * N, &oj[k * N], N * sizeof(double));

@@ -513,7 +513,8 @@ class BatchedPlanner:
         hh = None if height is None else np.ascontiguousarray(height, np.float64)
         res, o = {}, Outputs()
         for name in outputs:
-            res[name] = np.zeros(B, np.int32) if name == "status" else np.zeros((B, N))
+            # (per-instance integers start at -1 so that what the library writes can be told apart)
+            res[name] = np.full(B, -1, np.int32) if name in ("status", "iters", "n_active") else np.zeros((B, N))
             setattr(o, name, res[name].ctypes.data)
         _check(load_library().mpcb_solve_unconstrained_heights(
             self._h, B, x0.ctypes.data, zr.ctypes.data, None if hh is None else hh.ctypes.data, C.byref(o)))

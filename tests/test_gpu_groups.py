@@ -305,9 +305,13 @@ def test_unconstrained_form_with_a_height_per_instance(P, oracle):
     height = 0.4 + 0.2 * rng.uniform()
     height[3] = height[11] = 0.5
     pl = P.BatchedPlanner(N, formulation=P.UNCONSTRAINED, weight_R=1e-6, weight_Q=1.0, height=0.5)
-    o = pl.solve_unconstrained_host(x0, zref, height=height)
-    plain = pl.solve_unconstrained_host(x0, zref)
+    every = ("jerk_x", "zmp_x", "com_x", "com_xd", "status", "iters", "n_active")
+    o = pl.solve_unconstrained_host(x0, zref, height=height, outputs=every)
+    plain = pl.solve_unconstrained_host(x0, zref, outputs=every)
     assert (o["status"] == 0).all()
+    # solveQP iterates over nothing: both paths report no iterations and an empty working set
+    for r in (o, plain):
+        assert (r["iters"] == 0).all() and (r["n_active"] == 0).all()
     for i in range(B):
         p = oracle.params(N, R=1e-6, Q=1.0, height=float(height[i]))
         jerk = oracle.solve_qp(p, x0[i], zref[i])
