@@ -321,3 +321,56 @@ def test_unconstrained_form_with_a_height_per_instance(P, oracle):
         if height[i] == 0.5:
             assert np.array_equal(o["jerk_x"][i], plain["jerk_x"][i])
     assert _rel(o["jerk_x"][0], plain["jerk_x"][0]) > 1e-4  # the heights matter
+
+
+def test_height_groups_beyond_the_handle_cache(P):
+    """A handle keeps the tables of at most 1,024 heights it was asked for.  Three batches of 700
+    distinct heights each (the third repeats the first) push it over that limit twice: the tables
+    used longest ago are dropped, rebuilt when they are asked for again, and every instance still
+    gets the result of a planner created at its own height.  More than 1,024 distinct heights in
+    ONE batch are refused."""
+    N, B = 16, 700
+    rng = batches.SplitMix(np.arange(3 * B), seed=11)
+    x0 = np.stack([rng.uniform(0.0, 0.2), rng.uniform(-0.1, 0.1), np.zeros(3 * B)], axis=1)
+    zref = np.linspace(0, 0.1, N)[None, :] * (1.0 + rng.uniform(-0.3, 0.3))[:, None]
+    heights = 0.40 + 0.0001 * np.arange(2 * B)
+    pl = P.BatchedPlanner(N, formulation=P.UNCONSTRAINED, weight_R=1e-4, weight_Q=1.0, height=0.5)
+    rounds = [(slice(0, B), heights[:B]), (slice(B, 2 * B), heights[B:]), (slice(2 * B, 3 * B), heights[:B])]
+    for sl, hh in rounds:
+        o = pl.solve_unconstrained_host(x0[sl], zref[sl], height=hh)
+        assert (o["status"] == 0).all()
+        for i in (0, 1, B // 2, B - 1):
+            single = P.BatchedPlanner(N, formulation=P.UNCONSTRAINED, weight_R=1e-4, weight_Q=1.0, height=float(hh[i]))
+            ref = single.solve_unconstrained_host(x0[sl][i:i + 1], zref[sl][i:i + 1])
+            assert np.array_equal(o["jerk_x"][i], ref["jerk_x"][0]), i
+            assert np.array_equal(o["zmp_x"][i], ref["zmp_x"][0]), i
+    with pytest.raises(P.MpcError, match="distinct heights"):
+        pl.solve_unconstrained_host(np.tile(x0[:1], (1100, 1)), np.tile(zref[:1], (1100, 1)),
+                                    height=0.40 + 0.0001 * np.arange(1100))
+
+
+def test_groups_edge_cases_empty_groups_and_a_bad_parameter_set(P):
+    """An empty group between two others changes nothing; a parameter set that cannot be built
+    fails the whole mpcb_create_groups call, names the set and leaves no handle behind."""
+    import torch
+    pls = P.BatchedPlanner.create_groups([
+        dict(horizon=100, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=10),
+        dict(horizon=60, formulation=P.COUPLED_JERK, weight_R=0.02, number_of_steps=6),
+        dict(horizon=150, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=15)])
+    bts = [batches.coupled_batch(12, first=100), batches.coupled_batch(1, first=200), batches.coupled_batch(7, first=300)]
+    bts[1] = {k: v[:0] for k, v in bts[1].items()}  # nothing to solve for the middle group
+    prep = [pl.prepare_coupled(**bt) for pl, bt in zip(pls, bts)]
+    assert prep[1][0] == 0
+    outs = [pl._alloc_outputs(p[0], P.ALL_OUTPUTS) for pl, p in zip(pls, prep)]
+    res = P.BatchedPlanner.solve_coupled_groups(pls, prep, outs)
+    torch.cuda.synchronize()
+    for g in (0, 2):
+        alone = _np(pls[g].solve_coupled_prepared(prep[g]))
+        got = _np(res[g])
+        assert (got["status"] == 0).all()
+        for k, v in alone.items():
+            assert np.array_equal(got[k], v, equal_nan=True), (g, k)
+    with pytest.raises(P.MpcError, match="parameter set 1"):
+        P.BatchedPlanner.create_groups([
+            dict(horizon=100, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=10),
+            dict(horizon=100, formulation=P.COUPLED_VEL, weight_R=-1.0, weight_Q=1.0, number_of_steps=10)])
