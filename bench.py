@@ -667,6 +667,10 @@ def main():
                 r["executed_f64_gflop_per_launch"] = ex * scale / 1e9
                 r["achieved"] = ex * scale / kernel_s / 1e12
                 r["frac"] = r["achieved"] / peak_tf
+                if r["profiled_kernel_avg_ms"]:
+                    # the same arithmetic with the profile's own duration (rocprofv3 adds a few microseconds
+                    # to every launch): what someone recomputing from profiles/ alone arrives at
+                    r["frac_profile_duration"] = ex / (r["profiled_kernel_avg_ms"] / 1e3) / 1e12 / peak_tf
                 r["note"] = ("achieved = fp64 operations the kernel issued (SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 x 64 "
                              "lanes, FMA = 2; counter pass of the same kernel sources, see profile_source) / "
                              "average launch duration measured in this run with HIP events")
