@@ -46,6 +46,37 @@ def test_create_fails_loudly_without_gpu():
         planner.BatchedPlanner(20, formulation=planner.BOX_1D, weight_R=1.0)
 
 
+def test_argument_checks_need_no_gpu():
+    """Null pointers, empty lists and unknown ids are refused with MPCB_E_ARG (-1) and a message before
+    anything touches a device, so these calls behave the same with and without a GPU."""
+    import ctypes as C
+    from mpc_amd import planner
+    lib = planner.load_library()
+    lib.mpcb_last_error.restype = C.c_char_p
+    one = C.c_void_p()
+    n1 = (C.c_int32 * 1)(1)
+    calls = [
+        lambda: lib.mpcb_create(None, C.byref(one)),
+        lambda: lib.mpcb_create_groups(None, 1, C.byref(one)),
+        lambda: lib.mpcb_create_groups(C.byref(planner.Params()), 0, C.byref(one)),
+        lambda: lib.mpcb_solve_coupled_groups(None, 1, n1, None, None, None),
+        lambda: lib.mpcb_solve_coupled_multi_device(None, 1, n1, None, None, None),
+        lambda: lib.mpcb_solve_coupled_multi(None, 1, 1, None, None),
+        lambda: lib.mpcb_solve_unconstrained_heights(None, 1, None, None, None, None),
+        lambda: lib.mpcb_solve_coupled_device_noalloc(None, 1, None, None, None),
+        lambda: lib.mpcb_debug_host_table(None, 0, None),
+    ]
+    for k, call in enumerate(calls):
+        assert call() == -1, k
+        assert lib.mpcb_last_error(), k
+    # a host-built table of a valid parameter set, and an id that does not exist
+    pr = planner.Params()
+    pr.horizon, pr.formulation, pr.Ts, pr.gravity, pr.height = 12, planner.BOX_1D, 0.1, 9.81, 0.5
+    pr.weight_R, pr.weight_Q, pr.weight_Qs, pr.replanning_window = 1.0, 1.0, 1.0, 1000
+    assert lib.mpcb_debug_host_table(C.byref(pr), 0, None) == 144
+    assert lib.mpcb_debug_host_table(C.byref(pr), 99, None) == -1
+
+
 def test_product_package_does_not_import_the_oracle():
     for root, _, files in os.walk(os.path.join(ROOT, "mpc_amd")):
         for f in files:
