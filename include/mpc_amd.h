@@ -296,15 +296,21 @@ int  mpcb_solve_unconstrained_heights(mpcb_handle h, int32_t B, const double *x0
                                       const double *height, const mpcb_outputs *out);
 
 /* Diagnostic, no counterpart in the reference: how many instances of the handle's most recent
- * solve the first-stage kernel handed over to the dense second-stage kernel (working set
- * beyond its capacity, or a numerically singular reduced system).  Waits for the device. */
+ * solve ended in the dense second-stage kernel's full method (working set beyond the capacity of
+ * everything in front of it, or a numerically singular reduced system).  Waits for the device. */
 int  mpcb_last_handover_count(mpcb_handle h);
 
 /* Diagnostic, no counterpart in the reference: how many instances of the handle's most recent
- * coupled solve outgrew the 32 working-set rows of the first-stage kernel and were solved by its
- * wide edition (60 rows, a quarter of the occupancy) instead; those beyond 60 rows are part of
- * mpcb_last_handover_count.  Always 0 for box problems.  Waits for the device. */
+ * coupled solve outgrew the 32 working-set rows of the first-stage kernel and were taken over by
+ * its wide edition (60 rows, a quarter of the occupancy); those beyond 60 rows are counted by
+ * mpcb_last_block_count as well.  Always 0 for box problems.  Waits for the device. */
 int  mpcb_last_wide_count(mpcb_handle h);
+
+/* Diagnostic, no counterpart in the reference: how many instances of the handle's most recent
+ * coupled solve outgrew the wide edition too and went to the block edition of the same method
+ * (one workgroup per QP, up to 160 rows; horizons up to 256).  What that could not finish either
+ * is part of mpcb_last_handover_count.  Waits for the device. */
+int  mpcb_last_block_count(mpcb_handle h);
 
 /* Scheduling only, no counterpart in the reference (which solves one QP at a time): the order in
  * which the first-stage kernel starts the instances of a batch.  Results do not depend on it.

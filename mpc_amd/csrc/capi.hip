@@ -62,8 +62,11 @@ constexpr size_t SCRATCH_R_OFF = SCRATCH_J_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BY
 // hand-over records of the first stage for its wide edition, one per instance (kernels.h)
 constexpr size_t SCRATCH_WARM_I_OFF = SCRATCH_R_OFF + NOALLOC_SLOTS * SCRATCH_SLOT_BYTES;
 constexpr size_t SCRATCH_WARM_D_OFF = SCRATCH_WARM_I_OFF + (size_t)NOALLOC_MAX_BATCH * mpcb::WARM_STRIDE * sizeof(int);
-constexpr size_t SCRATCH_BYTES = SCRATCH_WARM_D_OFF + (size_t)NOALLOC_MAX_BATCH * mpcb::WARM_STRIDE * sizeof(double); // 47.0 MiB
-static_assert(SCRATCH_WARM_D_OFF % 256 == 0 && SCRATCH_WARM_I_OFF % 256 == 0, "scratch sections stay aligned");
+// list of the instances the wide edition leaves to the block edition
+constexpr size_t SCRATCH_BLOCK_OFF = SCRATCH_WARM_D_OFF + (size_t)NOALLOC_MAX_BATCH * mpcb::WARM_STRIDE * sizeof(double);
+constexpr size_t SCRATCH_BYTES = SCRATCH_BLOCK_OFF + (size_t)NOALLOC_MAX_BATCH * sizeof(int); // 47.25 MiB
+static_assert(SCRATCH_WARM_D_OFF % 256 == 0 && SCRATCH_WARM_I_OFF % 256 == 0 && SCRATCH_BLOCK_OFF % 256 == 0,
+              "scratch sections stay aligned");
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 constexpr int MAX_DEVICES = 64;
 // Streams and events mpcb_solve_coupled_groups can spread its groups over besides the caller's
@@ -97,6 +100,7 @@ struct mpcb_handle_s {
     int slot_target = 16;    // slots wanted: raised to the largest hand-over count seen (<= 512)
     bool dense_in_lds = false; // the dense kernel keeps J and R in LDS: no HBM slots at all
     bool wide_fits = false;    // the wide edition of the first-stage kernel fits the LDS for this shape
+    bool block_fits = false;   // ... and behind it the block edition, run by the dense kernel's workgroups
     // the counter block is known to be zero (every completed solve leaves it so): no memset needed
     bool counters_clean = false;
     // longest-first dispatch of the first stage (mpcb_set_dispatch_hint): the permutation and the
@@ -425,9 +429,10 @@ static int create_finish(mpcb_handle h, const mpcb::TableSet *tables) {
         // N knots instead of the footstep phases: sized for the larger of the two.
         mpcb::DevSetup sized = ds;
         if (params->formulation == MPCB_COUPLED_REF && sized.N > sized.nref) sized.nref = sized.N;
-        const size_t lds = mpcb::dense_lds_bytes_needed(sized, &h->dense_in_lds);
         h->wide_fits = params->formulation != MPCB_BOX_1D && params->formulation != MPCB_BOX_SLACK &&
                        mpcb::zspace_wide_lds_bytes(sized) <= 160 * 1024 - 256;
+        h->block_fits = h->wide_fits && params->solver_mode != MPCB_MODE_DENSE && mpcb::block_edition_applies(sized);
+        const size_t lds = mpcb::dense_lds_bytes_needed(sized, &h->dense_in_lds, h->block_fits);
         if (lds > 160 * 1024)
             return fail(MPCB_E_ARG, "horizon / number_of_steps too large for this formulation: the dense "
                                     "second-stage kernel would need " + std::to_string(lds) +
@@ -546,10 +551,12 @@ int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
         HIP_TRY(hipStreamSynchronize(stream));
         if (h->ws.list) HIP_TRY(hipFree(h->ws.list));
         if (h->ws.wide_list) HIP_TRY(hipFree(h->ws.wide_list));
+        if (h->ws.block_list) HIP_TRY(hipFree(h->ws.block_list));
         if (h->ws.warm_i) HIP_TRY(hipFree(h->ws.warm_i));
         if (h->ws.warm_d) HIP_TRY(hipFree(h->ws.warm_d));
         h->ws.list = nullptr;
         h->ws.wide_list = nullptr;
+        h->ws.block_list = nullptr;
         h->ws.warm_i = nullptr;
         h->ws.warm_d = nullptr;
         h->list_capacity = 0;
@@ -558,6 +565,11 @@ int ensure_workspace(mpcb_handle h, int B, hipStream_t stream) {
         HIP_TRY(hipMalloc((void **)&h->ws.list, (size_t)cap * sizeof(int)));
         if (h->params.formulation != MPCB_BOX_1D && h->params.formulation != MPCB_BOX_SLACK && h->wide_fits)
             HIP_TRY(hipMalloc((void **)&h->ws.wide_list, (size_t)cap * sizeof(int)));
+        if (h->block_fits) {
+            HIP_TRY(hipMalloc((void **)&h->ws.block_list, (size_t)cap * sizeof(int)));
+            const char *e = std::getenv("MPCB_DEBUG_BLOCK_ROWS"); // (tests of the fall-through to the full method)
+            h->ws.block_rows = e ? std::atoi(e) : 1 << 30;
+        }
         const bool coupled_wide = h->params.formulation != MPCB_BOX_1D && h->params.formulation != MPCB_BOX_SLACK &&
                                   h->wide_fits;
         if ((mpcb::box_dense_applies(h->ds) || coupled_wide) && !std::getenv("MPCB_DEBUG_COLD_SECOND_STAGE")) { // hand-over records, one per instance of the batch
@@ -681,6 +693,7 @@ int enqueue_two_stage(mpcb_handle h, const mpcb::DevIn &di, const mpcb_outputs &
         mpcb::DenseWs cold = ws;
         cold.warm_i = nullptr;
         cold.warm_d = nullptr;
+        cold.block_list = nullptr;
         HIP_TRY(mpcb::launch_list_all(cold, B, stream));
         HIP_TRY(mpcb::launch_dense(h->ds, di, out, cold, dense_grid, stream));
         return 0;
@@ -726,6 +739,7 @@ void mpcb_destroy(mpcb_handle h) {
         for (void *p : h->dev_allocs) (void)hipFree(p);
         if (h->ws.list) (void)hipFree(h->ws.list);
         if (h->ws.wide_list) (void)hipFree(h->ws.wide_list);
+        if (h->ws.block_list) (void)hipFree(h->ws.block_list);
         if (h->ws.warm_i) (void)hipFree(h->ws.warm_i);
         if (h->ws.warm_d) (void)hipFree(h->ws.warm_d);
         if (h->ws.J) (void)hipFree(h->ws.J);
@@ -770,6 +784,16 @@ int mpcb_last_wide_count(mpcb_handle h) {
     int n = 0;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(&n, h->ws.count + mpcb::CNT_LAST_WIDE, sizeof(int), hipMemcpyDeviceToHost));
+    return n;
+}
+
+int mpcb_last_block_count(mpcb_handle h) {
+    if (!h) return fail(MPCB_E_ARG, "null handle");
+    if (!h->ws.count || !h->ws.block_list) return 0;
+    DeviceGuard guard(h->params.device);
+    int n = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&n, h->ws.count + mpcb::CNT_LAST_BLOCK, sizeof(int), hipMemcpyDeviceToHost));
     return n;
 }
 
@@ -946,6 +970,8 @@ int mpcb_solve_coupled_device_noalloc(mpcb_handle h, int32_t B, const mpcb_coupl
     ws.R = reinterpret_cast<double *>(ptr + SCRATCH_R_OFF);
     ws.warm_i = h->wide_fits ? reinterpret_cast<int *>(ptr + SCRATCH_WARM_I_OFF) : nullptr;
     ws.warm_d = h->wide_fits ? reinterpret_cast<double *>(ptr + SCRATCH_WARM_D_OFF) : nullptr;
+    ws.block_list = h->block_fits ? reinterpret_cast<int *>(ptr + SCRATCH_BLOCK_OFF) : nullptr;
+    ws.block_rows = 1 << 30;
     const int cap = h->dense_in_lds ? 512 : NOALLOC_SLOTS;
     // The scratch's counter block is cleared in front of every call (a 32-byte memset node, no
     // allocation): under stream capture a call is only recorded, so nothing can be remembered

@@ -23,6 +23,7 @@
 
 #include "device_common.h"
 #include "kernels.h"
+#include "zspace_block.h"
 #include <type_traits>
 
 namespace mpcb {
@@ -146,9 +147,26 @@ __global__ __launch_bounds__(T) void dense_kernel(DevSetup sd, DevIn in, mpcb_ou
         else return (size_t)k * n + i;
     };
 
-    const int count = *ws.count;
-    for (int entry = blockIdx.x; entry < count; entry += gridDim.x) {
-        const int inst = ws.list[entry];
+    // Coupled forms with HBM-resident factors: the instances that outgrew the wide edition of the
+    // wave-per-QP kernel (ws.block_list) come first and are tried with the block edition of that
+    // method (zspace_block.h), which needs nothing n x n; the full method below takes what that
+    // cannot finish, and then its own list.
+    const int count = ws.count[CNT_HANDOVER];
+    int nblock = 0;
+    if constexpr (POLY && !LDSJ) nblock = ws.block_list ? ws.count[CNT_BLOCK] : 0;
+    for (int entry = blockIdx.x; entry < nblock + count; entry += gridDim.x) {
+        int inst;
+        if constexpr (POLY && !LDSJ) {
+            if (entry < nblock) {
+                inst = ws.block_list[entry];
+                if (block_solve(sd, in, out, ws, inst, smem)) continue;
+                if (tid == 0) atomicAdd(ws.count + CNT_FELL, 1);
+            } else {
+                inst = ws.list[entry - nblock];
+            }
+        } else {
+            inst = ws.list[entry];
+        }
         // Cz = Cx - c Ca (MPCPlanner.cpp:58-63): with a height per instance the Toeplitz column of
         // Zu and the third column of Zx are shifted by c = height / gravity
         const bool hv = in.height != nullptr;
@@ -1060,7 +1078,7 @@ size_t dense_lds_bytes(const DevSetup &sd, bool ldsj) {
 
 } // namespace
 
-size_t dense_lds_bytes_needed(const DevSetup &sd, bool *in_lds) {
+size_t dense_lds_bytes_needed(const DevSetup &sd, bool *in_lds, bool with_block) {
     if (box_dense_applies(sd)) {
         if (in_lds) *in_lds = true;
         return box_dense_lds_bytes(sd) + 256;
@@ -1068,7 +1086,14 @@ size_t dense_lds_bytes_needed(const DevSetup &sd, bool *in_lds) {
     // 160 KB of LDS per workgroup at most; keep a margin for the static part
     const bool ldsj = dense_lds_bytes(sd, true) <= 160 * 1024 - 256;
     if (in_lds) *in_lds = ldsj;
-    return dense_lds_bytes(sd, ldsj) + 256;
+    size_t bytes = dense_lds_bytes(sd, ldsj);
+    if (with_block && !ldsj) bytes = std::max(bytes, block_lds_bytes(sd));
+    return bytes + 256;
+}
+
+bool block_edition_applies(const DevSetup &sd) {
+    if (box_dense_applies(sd) || !block_applies(sd)) return false;
+    return !(dense_lds_bytes(sd, true) <= 160 * 1024 - 256); // (LDS-resident dense factors: small problems)
 }
 
 hipError_t launch_list_all(const DenseWs &ws, int B, hipStream_t stream) {
@@ -1083,7 +1108,8 @@ hipError_t launch_dense(const DevSetup &sd, const DevIn &in, const mpcb_outputs 
     const bool poly = sd.form != MPCB_BOX_1D;
     // 160 KB of LDS per workgroup at most; keep a margin for the static part
     const bool ldsj = dense_lds_bytes(sd, true) <= 160 * 1024 - 256;
-    const size_t shmem = dense_lds_bytes(sd, ldsj);
+    size_t shmem = dense_lds_bytes(sd, ldsj);
+    if (ws.block_list && poly && !ldsj) shmem = std::max(shmem, block_lds_bytes(sd)); // its workgroups run the block edition first
     const void *fn;
     if (sd.form == MPCB_BOX_SLACK)
         fn = ldsj ? reinterpret_cast<const void *>(dense_kernel<2, true>)

@@ -358,11 +358,15 @@ __device__ __forceinline__ double unconstrained_cost_part(const DevSetup &sd, co
 __device__ __forceinline__ void retire_counters(int *counters, unsigned workgroups, int *host_count) {
     __threadfence();
     if (atomicAdd(counters + CNT_DONE, 1) == (int)workgroups - 1) {
-        if (host_count) *host_count = counters[CNT_HANDOVER];
-        counters[CNT_LAST_HANDOVER] = counters[CNT_HANDOVER];
+        // (the host sizes the next solve's workgroups by everything this kernel had to work through)
+        if (host_count) *host_count = counters[CNT_HANDOVER] + counters[CNT_BLOCK];
+        counters[CNT_LAST_HANDOVER] = counters[CNT_HANDOVER] + counters[CNT_FELL];
         counters[CNT_LAST_WIDE] = counters[CNT_WIDE];
+        counters[CNT_LAST_BLOCK] = counters[CNT_BLOCK];
         counters[CNT_HANDOVER] = 0;
         counters[CNT_WIDE] = 0;
+        counters[CNT_BLOCK] = 0;
+        counters[CNT_FELL] = 0;
         counters[CNT_DONE] = 0;
     }
 }

@@ -14,6 +14,9 @@ constexpr int STATUS_UNRESOLVED = 3;
 // Internal as well: the first edition of the wave-per-QP kernel ran out of rows for the working
 // set and leaves the instance to its wide edition.
 constexpr int STATUS_TO_WIDE = 4;
+// ... and the wide edition ran out of rows in turn: the instance goes to the block edition (one
+// workgroup per QP, zspace_block.h), which the dense kernel's workgroups run before the full method.
+constexpr int STATUS_TO_BLOCK = 5;
 
 struct DevSetup {
     int N, m, axes, form;
@@ -68,10 +71,13 @@ constexpr int WARM_PASSES = 34;
 constexpr int WARM_F = 32, WARM_FALG = 33, WARM_RNORM = 34;
 
 // Counter block of a solve (DenseWs::count points at its first entry).  The first stage counts its
-// hand-overs in [CNT_HANDOVER] and [CNT_WIDE]; the dense kernel, always the last launch of a solve,
-// has its last workgroup out copy both to the CNT_LAST_* entries (which the host reads) and zero
-// the block again, so that a solve finds the counters at zero without a memset of its own.
+// hand-overs in [CNT_HANDOVER] and [CNT_WIDE], its wide edition those to the block edition in
+// [CNT_BLOCK]; the dense kernel, always the last launch of a solve, has its last workgroup out copy
+// them to the CNT_LAST_* entries (which the host reads) and zero the block again, so that a solve
+// finds the counters at zero without a memset of its own.  [CNT_LAST_HANDOVER] counts the instances
+// the full method solved: its own list plus what the block edition passed on ([CNT_FELL]).
 constexpr int CNT_HANDOVER = 0, CNT_WIDE = 1, CNT_DONE = 2, CNT_LAST_HANDOVER = 3, CNT_LAST_WIDE = 4;
+constexpr int CNT_BLOCK = 5, CNT_LAST_BLOCK = 6, CNT_FELL = 7;
 constexpr int COUNTER_INTS = 8;
 
 struct DenseWs {
@@ -80,6 +86,10 @@ struct DenseWs {
     int *host_count;           // page-locked host int that receives the hand-over count of the solve, or NULL
     int *wide_list;            // coupled forms: instances the first edition of the wave-per-QP kernel
     int *wide_count;           //   leaves to its wide edition (working set beyond 32 rows), or NULL
+    int *block_list;           // coupled forms: instances the wide edition leaves to the block edition (beyond
+                               //   60 rows; counted in count[CNT_BLOCK]), or NULL
+    int block_rows;            // rows the block edition may hold before it passes an instance on (its
+                               //   capacity, or less: MPCB_DEBUG_BLOCK_ROWS, for tests of the fall-through)
     int *warm_i;               // [B][WARM_STRIDE] hand-over records (see above), or NULL
     double *warm_d;            // [B][WARM_STRIDE]
     int *order;                // dispatch order of the first stage: workgroup w solves instance order[w]
@@ -105,7 +115,8 @@ constexpr int ORDER_HEADER = 4; // ints before the per-instance bins; [0] = batc
 hipError_t launch_dispatch_order(const DenseWs &ws, int B, hipStream_t stream);
 
 // Enqueues the wide edition (60-row capacity, a quarter of the occupancy) over ws.wide_list with
-// `blocks` single-wave workgroups; what it cannot finish either joins ws.list.  A no-op for box
+// `blocks` single-wave workgroups; what outgrows it too joins ws.block_list (if there is one), what
+// it cannot finish for another reason joins ws.list.  A no-op for box
 // problems and when ws.wide_list is NULL.  LDS bytes one of its workgroups needs.
 hipError_t launch_zspace_wide(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int blocks,
                               const DenseWs &ws, hipStream_t stream);
@@ -127,9 +138,13 @@ size_t box_dense_lds_bytes(const DevSetup &sd);
 hipError_t launch_box_dense(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, const DenseWs &ws,
                             int blocks, hipStream_t stream);
 
-// LDS bytes one workgroup of the dense kernel needs for this shape (dynamic + static part);
+// LDS bytes one workgroup of the dense kernel needs for this shape (dynamic + static part; with
+// `with_block` also what the block edition, which its workgroups run first, needs);
 // *in_lds: whether it keeps J and R in LDS, in which case ws.J / ws.R are never touched.
-size_t dense_lds_bytes_needed(const DevSetup &sd, bool *in_lds);
+size_t dense_lds_bytes_needed(const DevSetup &sd, bool *in_lds, bool with_block = false);
+// Whether the block edition covers this shape (coupled form, HBM-resident dense factors, the knots
+// fit one workgroup).
+bool block_edition_applies(const DevSetup &sd);
 
 // MPCPlanner::solveQP for B instances (handle built with MPCB_UNCONSTRAINED).
 hipError_t launch_unconstrained(const DevSetup &sd, const double *x0, const double *zref,

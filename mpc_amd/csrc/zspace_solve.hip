@@ -1084,7 +1084,9 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
                 if (t == t2) { // full step: add the constraint (:392-426, add_constraint :450-513)
                     if (iq >= (POLY ? QL : QL_BOX)) {
                         // (a wide edition, where one follows, takes the instances that are merely too big)
-                        status = (!WIDE && wide_list) ? STATUS_TO_WIDE : STATUS_UNRESOLVED;
+                        // (`wide_list`: the next edition's list -- the wide edition's for the first, the
+                        // block edition's for the wide one)
+                        status = wide_list ? (WIDE ? STATUS_TO_BLOCK : STATUS_TO_WIDE) : STATUS_UNRESOLVED;
                         done = true;
                         break;
                     }
@@ -1197,7 +1199,7 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
     const bool solved = status == MPCB_OK || status == MPCB_ITER_CAP;
     if (status == STATUS_UNRESOLVED && lane_e == 0 && unresolved_list)
         unresolved_list[atomicAdd(unresolved_count, 1)] = inst_e; // re-solved by the dense kernel
-    if (status == STATUS_TO_WIDE && lane_e == 0) wide_list[atomicAdd(wide_count, 1)] = inst_e;
+    if (status == (WIDE ? STATUS_TO_BLOCK : STATUS_TO_WIDE) && lane_e == 0) wide_list[atomicAdd(wide_count, 1)] = inst_e;
     if constexpr (RECORD) {
         if (lane_e == 0) {
             // bin = running time on a logarithmic scale, 16 bins to the octave (hand-overs count as
@@ -1472,13 +1474,15 @@ template <int NPL, bool ROWS, bool HV>
 __global__ __launch_bounds__(64, 1) void zspace_wide_kernel(DevSetup sd, DevIn in, mpcb_outputs out,
                                                             const int *work_list, const int *work_count,
                                                             int *unresolved_list, int *unresolved_count,
-                                                            int *warm_i, double *warm_d) {
+                                                            int *warm_i, double *warm_d, int *block_list,
+                                                            int *block_count) {
     extern __shared__ double smem[];
     const int count = ufirst(*work_count);
     for (int entry = blockIdx.x; entry < count; entry += gridDim.x) {
         solve_instance<NPL, true, ROWS, HV, true, false>(sd, in, out, ufirst(work_list[entry]),
                                                          (int)(threadIdx.x & 63), smem, unresolved_list,
-                                                         unresolved_count, warm_i, warm_d, nullptr, nullptr, nullptr);
+                                                         unresolved_count, warm_i, warm_d, block_list, block_count,
+                                                         nullptr);
         wsync();
     }
 }
@@ -1532,8 +1536,10 @@ hipError_t launch_one_wide(const DevSetup &sd, const DevIn &in, const mpcb_outpu
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
+    // (per-instance heights are not the block edition's: those instances go on to the full method)
+    int *block_list = HV ? nullptr : ws.block_list;
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64), shmem, stream, sd, in, out, ws.wide_list, ws.wide_count, ws.list,
-                       ws.count, ws.warm_i, ws.warm_d);
+                       ws.count, ws.warm_i, ws.warm_d, block_list, ws.count + CNT_BLOCK);
     return hipGetLastError();
 }
 

@@ -25,7 +25,7 @@ DISPATCH_IN_ORDER, DISPATCH_LONGEST_FIRST = 0, 1
 EXPORTS = ("mpcb_create", "mpcb_destroy", "mpcb_last_error", "mpcb_num_constraints", "mpcb_num_phases",
            "mpcb_solve_coupled_device", "mpcb_solve_coupled", "mpcb_solve_box_device",
            "mpcb_solve_box", "mpcb_get_matrix", "mpcb_replan_sweep_device",
-           "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained", "mpcb_last_handover_count", "mpcb_last_wide_count",
+           "mpcb_solve_unconstrained_device", "mpcb_solve_unconstrained", "mpcb_last_handover_count", "mpcb_last_wide_count", "mpcb_last_block_count",
            "mpcb_solve_coupled_device_noalloc", "mpcb_solve_coupled_multi", "mpcb_debug_set_stamp_buffer",
            "mpcb_set_dispatch_hint", "mpcb_solve_coupled_multi_device", "mpcb_solve_coupled_groups",
            "mpcb_create_groups", "mpcb_debug_host_table", "mpcb_solve_unconstrained_heights")
@@ -96,6 +96,7 @@ def load_library():
         lib.mpcb_get_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.mpcb_last_handover_count.argtypes = [C.c_void_p]
         lib.mpcb_last_wide_count.argtypes = [C.c_void_p]
+        lib.mpcb_last_block_count.argtypes = [C.c_void_p]
         lib.mpcb_set_dispatch_hint.argtypes = [C.c_void_p, C.c_int32]
         lib.mpcb_solve_unconstrained_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                                         C.POINTER(Outputs), C.c_void_p]
@@ -269,6 +270,11 @@ class BatchedPlanner:
         """Instances of the most recent coupled solve that the wide edition of the first-stage kernel took
         over (working sets of 33 to 60 rows)."""
         return _check(load_library().mpcb_last_wide_count(self._h))
+
+    def last_block_count(self):
+        """Instances of the most recent coupled solve that outgrew the wide edition as well and went
+        to the block edition (working sets of 61 to 160 rows)."""
+        return _check(load_library().mpcb_last_block_count(self._h))
 
     def last_handover_count(self):
         """Instances of the most recent solve that went through the dense second-stage kernel."""

@@ -30,3 +30,38 @@ for R in (1e-6, 1e-4):
           "working sets up to %d rows, status %s" %
           (R, ms, B, pl.last_wide_count(), pl.last_handover_count(), int(o["iters"].sum().item()),
            int(o["n_active"].max().item()), torch.bincount(o["status"]).tolist()))
+
+# Beyond 60 rows: weight_R = 1e-8 at three times the walking speed pushes a few working sets past
+# the wide edition's capacity.  The
+# batch is timed whole and again without the instances that went to the dense stage: the difference
+# is what those few cost.
+B = 2048
+bt = batches.coupled_batch(B)
+bt["speed"] = bt["speed"] * 3.0
+pl = P.BatchedPlanner(200, formulation=P.COUPLED_VEL, weight_R=1e-8, weight_Q=1.0, number_of_steps=20)
+
+
+def timed(sub):
+    prep = pl.prepare_coupled(**sub)
+    n = prep[0]
+    out = pl._alloc_outputs(n, P.ALL_OUTPUTS)
+    for _ in range(3):
+        pl.solve_coupled_prepared(prep, out=out)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(10):
+        pl.solve_coupled_prepared(prep, out=out)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / 10 * 1e3, out[0]
+
+
+ms_all, o = timed(bt)
+dense = pl.last_handover_count()
+block = pl.last_block_count()
+big = (o["n_active"] > 60).cpu().numpy() | (o["status"] != 0).cpu().numpy()
+keep = ~big
+ms_rest, _ = timed({k: v[keep] for k, v in bt.items()})
+print("weight_R 1e-8, speed x 3: %.3f ms per solve of %d instances (block edition %d, dense stage %d, working sets up to %d rows, status %s); "
+      "%.3f ms without the %d instances that end with more than 60 rows (dense stage then %d)" %
+      (ms_all, B, block, dense, int(o["n_active"].max().item()), torch.bincount(o["status"]).tolist(), ms_rest, int(big.sum()),
+       pl.last_handover_count()))

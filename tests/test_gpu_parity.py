@@ -437,7 +437,7 @@ def test_large_working_sets_wide_edition_and_dense_fallback(P, oracle):
     exceed the 32 rows of the first-stage kernel, so part of the batch is taken over mid-solve by
     its wide edition (60 rows): every output, the jerk included, to 1e-6 of the CPU restatement,
     identical iteration counts and working sets.  At weight_R = 1e-8 and three times the walking
-    speed one working set reaches 74 rows and goes on to the dense kernel; cond(G) ~ 1e12 there and
+    speed one working set reaches 74 rows and goes on to the block edition; cond(G) ~ 1e12 there and
     the CPU restatement's double-precision Cholesky (the reference's, eiquadprog.hpp:165) is itself
     only good to ~1e-4, which is the tolerance of that comparison -- the GPU's own answer is held
     to the optimality conditions instead, evaluated in extended precision."""
@@ -454,7 +454,9 @@ def test_large_working_sets_wide_edition_and_dense_fallback(P, oracle):
                                    bt["swing0"], active_stride=128, nthreads=16)
         assert (o["status"] == ref["status"]).all() and (ref["n_active"] > 32).any()
         assert pl.last_wide_count() >= (ref["n_active"] > 32).sum()
-        assert (pl.last_handover_count() > 0) == beyond_wide == bool((ref["n_active"] > 60).any())
+        # beyond 60 rows: the block edition of the same method (one workgroup per QP), not the full method
+        assert (pl.last_block_count() > 0) == beyond_wide == bool((ref["n_active"] > 60).any())
+        assert pl.last_handover_count() == 0
         assert (o["iters"] == ref["iters"]).all()
         assert np.allclose(o["alg_flops"], ref["falg"], rtol=1e-12)
         for i in range(B):
@@ -488,6 +490,67 @@ def test_large_working_sets_wide_edition_and_dense_fallback(P, oracle):
             assert float(np.abs(grad).max() / max(np.abs(g0).max(), np.abs(Gx).max())) < 1e-9
             assert float(u.min()) > -1e-9 and float(np.abs(u * sres[act]).max()) < 1e-6
             assert float(np.minimum(0, sres).sum()) > -pl_psi_threshold(G1, len(ci0))
+
+
+def test_block_edition_beyond_sixty_rows(P, oracle, monkeypatch):
+    """Working sets of 61 to ~130 rows (weight_R = 1e-8, three times the walking speed): the block
+    edition of the multiplier-space method -- one workgroup per QP behind the two wave-per-QP editions
+    -- must follow the CPU restatement's path exactly (status, iteration count, ordered working set,
+    operation count) and the full method must see none of them; trajectories to 1e-4, the accuracy
+    of the restatement's own double-precision Cholesky at cond(G) ~ 1e12 (see the test above).
+    Also: the ZMP-reference form and caller-built rows through the same stage, and the fall-through
+    to the full method when the stage's capacity (lowered for the test) is exceeded."""
+    N, steps, B = 200, 20, 192
+    bt = batches.coupled_batch(B, first=2000)
+    bt["speed"] = bt["speed"] * 3.0
+
+    def check(pl, ref, tol, label):
+        o = _np(pl.solve_coupled(**bt))
+        assert (o["status"] == ref["status"]).all(), label
+        assert (o["iters"] == ref["iters"]).all(), label
+        assert np.allclose(o["alg_flops"], ref["falg"], rtol=1e-12), label
+        for i in range(B):
+            na = ref["n_active"][i]
+            assert o["n_active"][i] == na, (label, i)
+            assert list(o["active_idx"][i, :na]) == list(ref["active"][i, :na]), (label, i)
+            for k in ("com_x", "com_y", "zmp_x", "zmp_y", "jerk_x", "jerk_y"):
+                assert _rel(o[k][i], ref[k][i]) < tol, (label, k, i, _rel(o[k][i], ref[k][i]))
+        assert (np.abs(o["cost"] - ref["cost"]) <= tol * np.abs(ref["cost"])).all(), label
+        return o
+
+    for form, oform, kw in (("COUPLED_VEL", "COUPLED_VEL", {}), ("COUPLED_REF", "COUPLED_REF", dict(weight_Qs=1e-4))):
+        pl = P.BatchedPlanner(N, formulation=getattr(P, form), weight_R=1e-8, weight_Q=1.0, number_of_steps=steps,
+                              active_stride=192, **kw)
+        ref = oracle.coupled_batch(oracle.params(N, R=1e-8, Q=1.0, Qs=kw.get("weight_Qs", 100.0), height=0.5,
+                                                 iter_cap=8000), getattr(oracle, oform), steps, 1000, bt["x0"],
+                                   bt["y0"], bt["speed"], bt["feet_x"], bt["feet_y"], bt["swing0"],
+                                   active_stride=192, nthreads=16)
+        beyond = int((ref["n_active"] > 60).sum())
+        assert beyond >= 3, (form, beyond)
+        check(pl, ref, 1e-4, form)
+        assert pl.last_block_count() >= beyond and pl.last_handover_count() == 0, form
+        if form == "COUPLED_VEL":
+            # the same rows handed in by the caller (A, b of computeSteps as (p, q, r) triples)
+            rows = np.zeros((B, pl.num_constraints, 3))
+            for i in range(B):
+                st = oracle.compute_steps(N, steps, bt["speed"][i], bt["feet_x"][i], bt["feet_y"][i], bt["swing0"][i])
+                A, b = st["A"], st["b"]
+                kn = np.array([np.nonzero(A[r])[0][0] % N for r in range(A.shape[0])])
+                rows[i, :, 0] = A[np.arange(A.shape[0]), kn]
+                rows[i, :, 1] = A[np.arange(A.shape[0]), kn + N]
+                rows[i, :, 2] = b
+            o2 = _np(pl.solve_coupled(bt["x0"], bt["y0"], bt["speed"], rows_pqr=rows))
+            assert (o2["status"] == ref["status"]).all() and (o2["iters"] == ref["iters"]).all()
+            assert pl.last_block_count() >= beyond and pl.last_handover_count() == 0
+            big = int(np.argmax(ref["n_active"]))
+            assert list(o2["active_idx"][big, :ref["n_active"][big]]) == list(ref["active"][big, :ref["n_active"][big]])
+            # a lower capacity for the stage: what exceeds it goes on to the full method, same answers
+            monkeypatch.setenv("MPCB_DEBUG_BLOCK_ROWS", "70")
+            low = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=1e-8, weight_Q=1.0, number_of_steps=steps,
+                                   active_stride=192)
+            check(low, ref, 1e-4, "capacity 70")
+            assert low.last_handover_count() == int((ref["n_active"] > 70).sum()) > 0
+            monkeypatch.delenv("MPCB_DEBUG_BLOCK_ROWS")
 
 
 def pl_psi_threshold(G1, m):

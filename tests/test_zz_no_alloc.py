@@ -1,8 +1,8 @@
 """The entry point that allocates nothing (static device scratch instead of the handle's
 hipMalloc'd lists and dense workspace) returns, bit for bit, what mpcb_solve_coupled_device
 returns -- on two calls in a row, the second with a smaller batch, with instances going through
-the wide edition of the first-stage kernel (the scratch's second list) and through the dense
-second stage (the scratch's J / R slots)."""
+the wide edition of the first-stage kernel (the scratch's second list), through the block edition
+behind it (the third list) and through the dense second stage (the scratch's J / R slots)."""
 import numpy as np
 import pytest
 
@@ -20,12 +20,14 @@ def P():
     return planner
 
 
-def _compare(P, pl, B, first, expect_handover, expect_wide=False):
+def _compare(P, pl, B, first, expect_handover, expect_wide=False, speed_scale=1.0, expect_block=False):
     import torch
     bt = batches.coupled_batch(B, first=first)
+    bt["speed"] = bt["speed"] * speed_scale
     prepared = pl.prepare_coupled(**bt)
     ref = {k: v.cpu().numpy() for k, v in pl.solve_coupled_prepared(prepared).items()}
     handed, wide = pl.last_handover_count(), pl.last_wide_count()
+    assert (pl.last_block_count() > 0) == expect_block
     out = pl._alloc_outputs(B, P.ALL_OUTPUTS)
     for t in out[0].values():  # whatever the call does not write must show up
         t.fill_(-7)
@@ -57,6 +59,11 @@ def test_no_alloc_entry_point_matches_allocating_one(P):
     _compare(P, easy, 96, 0, False)
     _compare(P, easy, 33, 96, False)
     _compare(P, hard, 20, 900, False, True)  # and the first handle again, after others used the scratch
+    # working sets beyond 60 rows (weight_R = 1e-8, three times the walking speed): the wide edition
+    # passes them on through the scratch's third list to the block edition
+    harder = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=1e-8, weight_Q=1.0, number_of_steps=steps)
+    _compare(P, harder, 64, 0, False, True, speed_scale=3.0, expect_block=True)
+    _compare(P, harder, 8, 0, False, True, speed_scale=3.0, expect_block=True)
     # a handle set to longest-first dispatch: the allocating path orders its launch (second call on:
     # from the record of the one before), the no-alloc path always runs in index order -- same results
     easy.set_dispatch_hint(P.DISPATCH_LONGEST_FIRST)
