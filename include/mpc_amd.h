@@ -191,7 +191,7 @@ int  mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in,
  * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No
  * counterpart in the reference.  mpcb_solve_coupled_device sizes its hand-over list and the
  * dense second stage's J / R slots with hipMalloc on first use and when a batch outgrows them;
- * this entry point keeps them in a static device array instead (47.0 MiB per GPU, held from
+ * this entry point keeps them in a static device array instead (47.25 MiB per GPU, held from
  * the moment the library is loaded on that GPU until the process ends) and calls no hipMalloc,
  * hipFree or other allocating routine.  Limits, rejected with MPCB_E_ARG: B <= 65536 and at
  * most 400 variables per QP (horizon <= 200); the dense stage has 8 slots, so a batch that

@@ -229,8 +229,20 @@ __device__ __forceinline__ bool block_solve(const DevSetup &sd, const DevIn &in,
 
     // zmp (or, with the W table, jerk) response to the first n working-set rows with the
     // coefficients in cx, cy, added to (vx, vy)
+    // (sixteen rows' loads in flight per thread: with one workgroup on the compute unit there is
+    // nothing else to hide the trip to L2 behind)
     auto accum_rows = [&](const double *M, int n, double &vx, double &vy) {
         int a = 0;
+        for (; a + 16 <= n; a += 16) {
+            double s[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) s[j] = M[(size_t)(KS[a + j] >> 2) * N + kc];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                vx += cx[a + j] * s[j];
+                vy += cy[a + j] * s[j];
+            }
+        }
         for (; a + 4 <= n; a += 4) {
             double s[4];
 #pragma unroll
@@ -407,15 +419,39 @@ __device__ __forceinline__ bool block_solve(const DevSetup &sd, const DevIn &in,
                 if (tid < iq) gv[tid] = (Pp[tid] * pip + Qq[tid] * qip) * sd.S[(size_t)kip * N + (KS[tid] >> 2)];
                 __syncthreads();
                 double da = 0.0;
+                // (eight terms' loads are issued before the first of them is used: taken one by one each
+                // term would wait out the LDS latency)
                 if (tid < iq) {
                     const double *col = Tp + btri(tid);
-                    for (int j = 0; j <= tid; j++) da = fma(col[j], gv[j], da);
+                    int j = 0;
+                    for (; j + 8 <= tid + 1; j += 8) {
+                        double t[8], g[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            t[e] = col[j + e];
+                            g[e] = gv[j + e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; e++) da = fma(t[e], g[e], da);
+                    }
+                    for (; j <= tid; j++) da = fma(col[j], gv[j], da);
                     dv[tid] = da;
                 }
                 __syncthreads();
                 double ra = 0.0, ua = 0.0;
                 if (tid < iq) {
-                    for (int c = tid; c < iq; c++) ra = fma(Tp[btri(c) + tid], dv[c], ra);
+                    int c = tid;
+                    for (; c + 8 <= iq; c += 8) {
+                        double t[8], d8[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            t[e] = Tp[btri(c + e) + tid];
+                            d8[e] = dv[c + e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; e++) ra = fma(t[e], d8[e], ra);
+                    }
+                    for (; c < iq; c++) ra = fma(Tp[btri(c) + tid], dv[c], ra);
                     ua = U[tid];
                 }
                 // z . n_ip and step 2b: t1 = min u_k / r_k over r_k > 0, first minimum wins (:322-334)
