@@ -13,6 +13,8 @@
 // (DenseWs::block_list) before they fall back to the full method, which still takes what exceeds
 // 160 rows or loses the reduced system's accuracy.
 #pragma once
+#include <type_traits>
+
 #include "device_common.h"
 #include "kernels.h"
 
@@ -146,6 +148,19 @@ __device__ __forceinline__ bool block_solve(const DevSetup &sd, const DevIn &in,
         wx[3] = in.speed[(size_t)inst * 2];
         wy[3] = in.speed[(size_t)inst * 2 + 1];
     }
+    // A CoM height per instance (in.height): the response tables are combined from their height-free
+    // parts as they are read, S = Spp - c Sps + c^2 Saa, W^T = Wtp - c Wta, Kz = Kzp - c Kza with
+    // c = height / gravity, in the same arithmetic as the wave-per-QP kernel.
+    const bool hv = in.height != nullptr;
+    const double ch = hv ? in.height[inst] * sd.inv_gravity : 0.0, ch2 = ch * ch;
+    auto S_at = [&](int r, int c) -> double {
+        const size_t o = (size_t)r * N + c;
+        return hv ? fma(ch2, sd.Saa[o], fma(-ch, sd.Sps[o], sd.Spp[o])) : sd.S[o];
+    };
+    auto W_at = [&](int r, int c) -> double {
+        const size_t o = (size_t)r * N + c;
+        return hv ? fma(-ch, sd.Wta[o], sd.Wtp[o]) : sd.Wt[o];
+    };
     const double *rows = in.rows_pqr ? in.rows_pqr + (size_t)inst * m * 3 : nullptr;
     if (!rows)
         for (int pb = 0; pb < sd.nphase; pb += BT_) polygon_phase(sd, in, inst, wx[3], wy[3], pb + tid, tab, cref);
@@ -186,7 +201,10 @@ __device__ __forceinline__ bool block_solve(const DevSetup &sd, const DevIn &in,
     // ---- unconstrained solution (x = -G^-1 g0, eiquadprog.hpp:188-191) ------------------------
     double zxu, zyu;
     {
-        const double *kz = sd.Kz + (size_t)kc * 4;
+        double kz[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+            kz[a] = hv ? fma(-ch, sd.Kza[(size_t)kc * 4 + a], sd.Kzp[(size_t)kc * 4 + a]) : sd.Kz[(size_t)kc * 4 + a];
         zxu = kz[0] * wx[0] + kz[1] * wx[1] + kz[2] * wx[2] + kz[3] * wx[3];
         zyu = kz[0] * wy[0] + kz[1] * wy[1] + kz[2] * wy[2] + kz[3] * wy[3];
         if (sd.Sp)
@@ -231,12 +249,14 @@ __device__ __forceinline__ bool block_solve(const DevSetup &sd, const DevIn &in,
     // coefficients in cx, cy, added to (vx, vy)
     // (sixteen rows' loads in flight per thread: with one workgroup on the compute unit there is
     // nothing else to hide the trip to L2 behind)
-    auto accum_rows = [&](const double *M, int n, double &vx, double &vy) {
+    auto accum_rows = [&](auto wtag, int n, double &vx, double &vy) {
+        constexpr bool WT = decltype(wtag)::value; // the jerk response W^T instead of the ZMP response S
+        auto M_at = [&](int r) -> double { return WT ? W_at(r, kc) : S_at(r, kc); };
         int a = 0;
         for (; a + 16 <= n; a += 16) {
             double s[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++) s[j] = M[(size_t)(KS[a + j] >> 2) * N + kc];
+            for (int j = 0; j < 16; j++) s[j] = M_at(KS[a + j] >> 2);
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 vx += cx[a + j] * s[j];
@@ -246,7 +266,7 @@ __device__ __forceinline__ bool block_solve(const DevSetup &sd, const DevIn &in,
         for (; a + 4 <= n; a += 4) {
             double s[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) s[j] = M[(size_t)(KS[a + j] >> 2) * N + kc];
+            for (int j = 0; j < 4; j++) s[j] = M_at(KS[a + j] >> 2);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 vx += cx[a + j] * s[j];
@@ -254,7 +274,7 @@ __device__ __forceinline__ bool block_solve(const DevSetup &sd, const DevIn &in,
             }
         }
         for (; a < n; a++) {
-            const double s = M[(size_t)(KS[a] >> 2) * N + kc];
+            const double s = M_at(KS[a] >> 2);
             vx += cx[a] * s;
             vy += cy[a] * s;
         }
@@ -351,7 +371,7 @@ __device__ __forceinline__ bool block_solve(const DevSetup &sd, const DevIn &in,
         __syncthreads();
         zx = zxu;
         zy = zyu;
-        accum_rows(sd.S, iq, zx, zy);
+        accum_rows(std::false_type{}, iq, zx, zy);
         // s(x) for every row (:255-261) and the sum of the violations
         double sv[4], psi = 0.0;
 #pragma unroll
@@ -404,7 +424,7 @@ __device__ __forceinline__ bool block_solve(const DevSetup &sd, const DevIn &in,
             qip = row_q(ipKS);
             ucand = 0.0; // u(iq) = 0 (:297)
             pending = true;
-            const double skk = sd.S[(size_t)kip * N + kip];
+            const double skk = S_at(kip, kip);
             const double mii = (pip * pip + qip * qip) * skk; // n_ip' G^-1 n_ip
 
             for (;;) { // step 2a (l2a), :306-446
@@ -416,7 +436,7 @@ __device__ __forceinline__ bool block_solve(const DevSetup &sd, const DevIn &in,
                 }
                 falg += 2 * nn * nn + 2 * nn * (nn - iq) + (long long)iq * iq;
                 // g = N_A' G^-1 n_ip ; d = R^-T g (= J1' n_ip) ; r = R^-1 d
-                if (tid < iq) gv[tid] = (Pp[tid] * pip + Qq[tid] * qip) * sd.S[(size_t)kip * N + (KS[tid] >> 2)];
+                if (tid < iq) gv[tid] = (Pp[tid] * pip + Qq[tid] * qip) * S_at(kip, KS[tid] >> 2);
                 __syncthreads();
                 double da = 0.0;
                 // (eight terms' loads are issued before the first of them is used: taken one by one each
@@ -475,9 +495,9 @@ __device__ __forceinline__ bool block_solve(const DevSetup &sd, const DevIn &in,
                         cy[tid] = -ra * Qq[tid];
                     }
                     __syncthreads();
-                    const double w = sd.Wt[(size_t)kip * N + kc];
+                    const double w = W_at(kip, kc);
                     double zvx = pip * w, zvy = qip * w;
-                    accum_rows(sd.Wt, iq, zvx, zvy);
+                    accum_rows(std::true_type{}, iq, zvx, zvy);
                     znz = fabs(blk_sum(kv ? zvx * zvx + zvy * zvy : 0.0, red, tid)) > EPS;
                 }
                 if (znz && !(zn > 1e-7 * mii)) {
@@ -616,7 +636,7 @@ __device__ __forceinline__ bool block_solve(const DevSetup &sd, const DevIn &in,
                 jx += cref[2 * p] * w;
                 jy += cref[2 * p + 1] * w;
             }
-        accum_rows(sd.Wt, nresp, jx, jy);
+        accum_rows(std::true_type{}, nresp, jx, jy);
         if (kv) {
             if (out.jerk_x) out.jerk_x[o] = solved ? jx : 0.0;
             if (out.jerk_y) out.jerk_y[o] = solved ? jy : 0.0;
@@ -651,7 +671,7 @@ __device__ __forceinline__ bool block_solve(const DevSetup &sd, const DevIn &in,
         if (!zmp_current) {
             zx = zxu;
             zy = zyu;
-            accum_rows(sd.S, nresp, zx, zy);
+            accum_rows(std::false_type{}, nresp, zx, zy);
         }
         if (kv) {
             if (out.zmp_x) out.zmp_x[o] = solved ? zx : 0.0;

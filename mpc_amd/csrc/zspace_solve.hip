@@ -1536,10 +1536,8 @@ hipError_t launch_one_wide(const DevSetup &sd, const DevIn &in, const mpcb_outpu
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    // (per-instance heights are not the block edition's: those instances go on to the full method)
-    int *block_list = HV ? nullptr : ws.block_list;
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64), shmem, stream, sd, in, out, ws.wide_list, ws.wide_count, ws.list,
-                       ws.count, ws.warm_i, ws.warm_d, block_list, ws.count + CNT_BLOCK);
+                       ws.count, ws.warm_i, ws.warm_d, ws.block_list, ws.count + CNT_BLOCK);
     return hipGetLastError();
 }
 

@@ -551,6 +551,25 @@ def test_block_edition_beyond_sixty_rows(P, oracle, monkeypatch):
             check(low, ref, 1e-4, "capacity 70")
             assert low.last_handover_count() == int((ref["n_active"] > 70).sum()) > 0
             monkeypatch.delenv("MPCB_DEBUG_BLOCK_ROWS")
+            # a CoM height per instance through the same stage: each instance against the restatement
+            # run at its own height
+            Bh = 32
+            hh = 0.45 + 0.1 * batches.SplitMix(np.arange(Bh), seed=3).uniform()
+            pick = np.argsort(-ref["n_active"], kind="stable")[:Bh]  # the instances with the largest working sets
+            sub = {k: v[pick] for k, v in bt.items()}
+            oh = _np(pl.solve_coupled(height=hh, **sub))
+            assert pl.last_handover_count() == 0
+            assert (pl.last_block_count() > 0) == bool((oh["n_active"] > 60).any()) and (oh["n_active"] > 60).any()
+            for i in range(Bh):
+                r1 = oracle.coupled_batch(oracle.params(N, R=1e-8, Q=1.0, height=float(hh[i]), iter_cap=8000),
+                                          oracle.COUPLED_VEL, steps, 1000, sub["x0"][i:i + 1], sub["y0"][i:i + 1],
+                                          sub["speed"][i:i + 1], sub["feet_x"][i:i + 1], sub["feet_y"][i:i + 1],
+                                          sub["swing0"][i:i + 1], active_stride=192)
+                na = r1["n_active"][0]
+                assert oh["status"][i] == r1["status"][0] and oh["iters"][i] == r1["iters"][0], i
+                assert list(oh["active_idx"][i, :na]) == list(r1["active"][0, :na]), i
+                for k in ("com_x", "zmp_y", "jerk_x"):
+                    assert _rel(oh[k][i], r1[k][0]) < 1e-4, (k, i)
 
 
 def pl_psi_threshold(G1, m):
