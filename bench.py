@@ -269,6 +269,7 @@ class DecoupledWorkload:
         if parts:
             self.X_PARTS = parts
         self.B = B
+        self.first, self.dev = first, dev
         self.name = "decoupled"
         self.inputs = batches.decoupled_batch(B, N=self.N, steps=10, first=first)
         # one handle per axis: a handle is bound to one stream at a time, and the two axes of a
@@ -369,6 +370,27 @@ class DecoupledWorkload:
         dt = (time.perf_counter() - t) / steps
         self.px, self.py, self.outx, self.outy, self.outx_part, self.inputs, self.parts, self.pl_more = keep
         return {"pairs": n, "value": n / dt, "unit": "solves/s", "ms_per_step": dt * 1e3}
+
+    def alternating_sets(self, steps):
+        """The same K steps issued alternately to two complete sets of handles, streams and outputs,
+        so that a step's first stage runs while the previous step's second stage -- one long
+        instance on one compute unit for most of its time -- is still finishing.  What a caller that
+        streams batches gets by alternating handles; not `value`, whose steps each run on one set."""
+        twin = DecoupledWorkload(self.B, self.first, self.dev, split=self.parts > 1, parts=self.parts)
+        sets = (self, twin)
+        for k in range(4):
+            sets[k % 2].step()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for k in range(steps):
+            sets[k % 2].step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / steps
+        same = all(bool((twin.outx[0][k] == self.outx[0][k]).all().item()) for k in ("status", "iters", "jerk_x"))
+        return {"value": self.B / dt, "unit": "solves/s", "ms_per_step": dt * 1e3, "sets": 2,
+                "results_identical": same,
+                "note": "K steps issued alternately to two sets of handles, streams and output arrays (no waits "
+                        "between them): consecutive steps overlap"}
 
     def cpu_baseline(self, threads, sample):
         from oracle import oracle as O
@@ -636,6 +658,8 @@ def main():
             line["pipelined_sub_batches"] = pipelined
         if world == 1 and args.host_steps > 0 and hasattr(wl, "host_buffers"):
             line["host_buffers"] = wl.host_buffers(args.host_steps)
+        if hasattr(wl, "alternating_sets") and not args.plain and world == 1:
+            line["alternating_sets"] = wl.alternating_sets(args.steps)
         if hasattr(wl, "feasible_subset") and not args.plain:
             line["feasible_subset"] = wl.feasible_subset()
         prof, prof_file = measured_profile(args.workload)
