@@ -544,6 +544,23 @@ def test_block_edition_beyond_sixty_rows(P, oracle, monkeypatch):
             assert pl.last_block_count() >= beyond and pl.last_handover_count() == 0
             big = int(np.argmax(ref["n_active"]))
             assert list(o2["active_idx"][big, :ref["n_active"][big]]) == list(ref["active"][big, :ref["n_active"][big]])
+            # ... and in the schedule-free layout (number_of_steps = 0: four slots per knot, empty slot =
+            # (0, 0, +inf)), where the same rows have other numbers: same plans
+            free = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=1e-8, weight_Q=1.0, number_of_steps=0,
+                                    active_stride=192)
+            assert free.num_constraints == 4 * N
+            rows4 = np.zeros((B, 4 * N, 3))
+            rows4[:, :, 2] = np.inf
+            slot = np.zeros(N, dtype=int)
+            for r, k in enumerate(kn):  # (the knot of every row is the same for every instance)
+                rows4[:, 4 * k + slot[k]] = rows[:, r]
+                slot[k] += 1
+            o4 = _np(free.solve_coupled(bt["x0"], bt["y0"], bt["speed"], rows_pqr=rows4))
+            assert (o4["status"] == ref["status"]).all() and (o4["iters"] == ref["iters"]).all()
+            assert (o4["n_active"] == ref["n_active"]).all() and free.last_block_count() >= beyond
+            assert free.last_handover_count() == 0
+            for k in ("com_x", "com_y", "zmp_x", "zmp_y"):
+                assert _rel(o4[k], o2[k]) < 1e-9, k
             # a lower capacity for the stage: what exceeds it goes on to the full method, same answers
             monkeypatch.setenv("MPCB_DEBUG_BLOCK_ROWS", "70")
             low = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=1e-8, weight_Q=1.0, number_of_steps=steps,
