@@ -65,9 +65,17 @@ struct WaveStateT {
 // WIDE: the second edition of this kernel, which takes over the instances whose working set
 // outgrows the 32 rows (coupled forms): 60 rows -- with the four padding entries that is one lane
 // per working-set position -- at a quarter of the occupancy (38 KB of LDS per wave).
-template <bool POLY, int NPL, bool WIDE>
+// SLIM: the first edition of the coupled forms at horizons up to 256 knots with the handle's own
+// height runs THREE waves per SIMD: 24 rows (10.8 KB of LDS per wave at 41 phases, twelve waves per
+// compute unit) and a budget of 168 registers, which the compiler meets with seven spilled dwords.
+// The third wave hides more of the per-iteration trips to L2 and LDS than the eight rows are worth:
+// working sets beyond 24 rows are rare at the benchmark's weights and are taken over mid-solve by
+// the wide edition.  (With a height per instance three tables are live per response entry and the
+// same budget spills ~35 dwords: those variants stay at two waves and 32 rows, like the box form.)
+template <bool POLY, int NPL, bool WIDE, bool HV>
 struct WaveConfig {
-    static constexpr int QL = WIDE ? 60 : 32;
+    static constexpr bool SLIM = POLY && !WIDE && !HV && NPL <= 4;
+    static constexpr int QL = WIDE ? 60 : SLIM ? 24 : 32;
     typedef WaveStateT<QL, !POLY> State;
     static_assert(POLY || QL <= WARM_QL, "a hand-over record holds the whole working set");
     static_assert(QL + 4 <= 64 && QL % 4 == 0, "one lane per working-set position; products run four terms per trip");
@@ -289,7 +297,8 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
     constexpr int ES = POLY ? 4 : 2;
     unsigned t_start = 0;
     if constexpr (RECORD) t_start = (unsigned)__builtin_amdgcn_s_memtime();
-    typedef typename WaveConfig<POLY, NPL, WIDE>::State WaveState;
+    typedef typename WaveConfig<POLY, NPL, WIDE, HV>::State WaveState;
+    constexpr bool SLIM = WaveConfig<POLY, NPL, WIDE, HV>::SLIM;
     constexpr int QL = WaveState::QL, LDI = WaveState::LDI;
     const int N = sd.N;
 #ifdef MPCB_STAMPS
@@ -540,7 +549,7 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
     auto ws_knots = [&]() -> int { return W.wsKS[lane < QL + 4 ? lane : 0]; };
     auto accum_rows = [&](auto wtag, int n, int ksv, double *vx, double *vy) {
         int a0 = 0;
-        if constexpr (NPL <= 4 && !HV) {
+        if constexpr (NPL <= 4 && !HV && !SLIM) { // (eight rows' loads do not fit the slim register budget)
             for (; n - a0 > 4; a0 += 8) accum_group(wtag, a0, ksv, vx, vy, std::integral_constant<int, 8>{});
         }
         for (; a0 < n; a0 += 4) accum_group(wtag, a0, ksv, vx, vy, std::integral_constant<int, 4>{});
@@ -1404,7 +1413,7 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
 
 // First edition: one QP per single-wave workgroup, instance = workgroup index.
 template <int NPL, bool POLY, bool ROWS, bool HV>
-__global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
+__global__ __launch_bounds__(64, NPL <= 4 ? ((POLY && !HV) ? 3 : 2) : 1) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
                                                       int *unresolved_list, int *unresolved_count,
                                                       int *warm_i, double *warm_d, int *wide_list,
                                                       int *wide_count) {
@@ -1419,7 +1428,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_kernel(DevSetup s
 // The same with a dispatch order: workgroup w solves instance order[w] and notes its running time
 // in order_record.
 template <int NPL, bool POLY, bool ROWS, bool HV>
-__global__ __launch_bounds__(64, NPL <= 4 ? 2 : 1) void zspace_ordered_kernel(DevSetup sd, DevIn in, mpcb_outputs out,
+__global__ __launch_bounds__(64, NPL <= 4 ? ((POLY && !HV) ? 3 : 2) : 1) void zspace_ordered_kernel(DevSetup sd, DevIn in, mpcb_outputs out,
                                                       int B, int *unresolved_list, int *unresolved_count,
                                                       int *warm_i, double *warm_d, int *wide_list,
                                                       int *wide_count, const int *order, int *order_record) {
@@ -1487,9 +1496,9 @@ __global__ __launch_bounds__(64, 1) void zspace_wide_kernel(DevSetup sd, DevIn i
     }
 }
 
-template <bool POLY, int NPL, bool WIDE>
+template <bool POLY, int NPL, bool WIDE, bool HV>
 size_t wave_lds_bytes(const DevSetup &sd) {
-    return sizeof(typename WaveConfig<POLY, NPL, WIDE>::State) +
+    return sizeof(typename WaveConfig<POLY, NPL, WIDE, HV>::State) +
            (POLY ? ((size_t)(sd.nphase + 1) * 12 + 2 * (size_t)std::max(sd.nphase, sd.nref)) * 8 : 0);
 }
 
@@ -1499,7 +1508,7 @@ hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &o
     // One wave (= one QP) per workgroup: waves never wait for each other, so a workgroup's LDS
     // and wave slot are released the moment its QP is done instead of when the slowest of
     // several is (iteration counts differ by 2-3x between instances).
-    const size_t shmem = wave_lds_bytes<POLY, NPL, false>(sd);
+    const size_t shmem = wave_lds_bytes<POLY, NPL, false, HV>(sd);
     // (the ordered edition exists for the library's own footstep inputs at the handle's height;
     // batches with caller-built rows or per-instance heights run in index order whatever the hint)
     if constexpr (!ROWS && !HV) {
@@ -1529,7 +1538,7 @@ hipError_t launch_one(const DevSetup &sd, const DevIn &in, const mpcb_outputs &o
 template <int NPL, bool ROWS, bool HV>
 hipError_t launch_one_wide(const DevSetup &sd, const DevIn &in, const mpcb_outputs &out, int blocks,
                            const DenseWs &ws, hipStream_t stream) {
-    const size_t shmem = wave_lds_bytes<true, NPL, true>(sd);
+    const size_t shmem = wave_lds_bytes<true, NPL, true, HV>(sd);
     auto kfn = zspace_wide_kernel<NPL, ROWS, HV>;
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
@@ -1596,8 +1605,8 @@ hipError_t launch_zspace_wide(const DevSetup &sd, const DevIn &in, const mpcb_ou
 
 size_t zspace_wide_lds_bytes(const DevSetup &sd) {
     const int npl = (sd.N + 63) / 64;
-    return npl <= 2 ? wave_lds_bytes<true, 2, true>(sd) : npl <= 4 ? wave_lds_bytes<true, 4, true>(sd)
-                                                                   : wave_lds_bytes<true, 8, true>(sd);
+    return npl <= 2 ? wave_lds_bytes<true, 2, true, false>(sd) : npl <= 4 ? wave_lds_bytes<true, 4, true, false>(sd)
+                                                                   : wave_lds_bytes<true, 8, true, false>(sd);
 }
 
 } // namespace mpcb
