@@ -819,10 +819,16 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
             zmp_current = true;
             break;
         }
-        if (lane < iq) { // :275-277
-            W.oldU[lane] = W.wsU[lane];
-            W.oldRow[lane] = W.wsRow[lane];
-            W.oldKS[lane] = W.wsKS[lane];
+        {
+            // (a fresh copy of the lane number: the addresses of these arrays would otherwise be
+            // computed once in front of the loop and kept -- in the slim build, spilled -- through it)
+            int lo_ = lane;
+            asm volatile("" : "+v"(lo_));
+            if (lo_ < iq) { // :275-277
+                W.oldU[lo_] = W.wsU[lo_];
+                W.oldRow[lo_] = W.wsRow[lo_];
+                W.oldKS[lo_] = W.wsKS[lo_];
+            }
         }
         // (coupled forms hand over with a record only when the working set is full at a full step,
         // and inside an outer iteration it can only shrink before that step)
@@ -853,6 +859,9 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
                     const int slot = mloc == mw ? mslot : -1;
                     const int ks = ((lane + 64 * (slot >> 2)) << 2) | (slot & 3);
                     const int key = slot < 0 ? 0x7fffffff : POLY ? ks : lane + 64 * (slot >> 2) + (slot & 3) * N;
+                    // (whether this lane's candidate is in the working set, taken here: past the tie
+                    // test only the key and this bit have to survive, not the slot)
+                    const int myact = (int)((actm >> (slot & 31)) & 1u);
                     // one lane attains the minimum unless rows tie exactly; only then does the
                     // lowest row have to be found across lanes
                     unsigned long long win = __ballot(slot >= 0);
@@ -863,8 +872,8 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
                     }
                     const int src = __ffsll((long long)win) - 1;
                     kmin = __builtin_amdgcn_readlane(key, src);
-                    const int act = __builtin_amdgcn_readlane((int)((actm >> (slot & 31)) & 1u), src);
-                    bks = __builtin_amdgcn_readlane(ks, src);
+                    const int act = __builtin_amdgcn_readlane(myact, src);
+                    bks = POLY ? kmin : __builtin_amdgcn_readlane(ks, src); // (the polygon rows' key is (knot, slot) itself)
                     if constexpr (POLY) {
                         // which of the winner lane's knots: a wave-uniform choice among
                         // readlanes (a per-lane choice would be an indexed register array)
@@ -894,7 +903,10 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
                 // nothing derived from them counts as loop-invariant: hoisted out of the main
                 // loop, the per-slot masks and keys would sit in registers -- or spill -- for
                 // the whole solve.)
-                unsigned elig = validm & ~actm & exclm;
+                // (rows the library builds itself: slots that do not exist evaluate to +inf through their
+                // table entries and are never below ss, so the mask of existing slots is not needed --
+                // and not kept alive through the main loop)
+                unsigned elig = ((POLY && !ROWS) ? 0xffffffffu : validm) & ~actm & exclm;
                 int lk = lane_k;
                 asm volatile("" : "+v"(elig), "+v"(lk));
 #pragma unroll
@@ -1398,7 +1410,7 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
                     double mn = DINF;
 #pragma unroll
                     for (int e = 0; e < ES; e++)
-                        if (validm & (1u << (4 * c + e)))
+                        if ((POLY && !ROWS) || (validm & (1u << (4 * c + e))))
                             mn = fmin(mn, slotP(c, e) * zx[c] + slotQ(c, e) * zy[c] + slotR(c, e));
                     out.min_margin[(size_t)inst_e * N + KN(c)] = solved ? mn : 0.0;
                 }
