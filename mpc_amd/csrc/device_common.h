@@ -81,14 +81,24 @@ __device__ __forceinline__ double wave_scan(double v) {
     return v;
 }
 
+// The hardware's minimum as one instruction.  fmin() on a value that comes out of a lane permute
+// is compiled to three: the compiler cannot see that the permuted bits are a canonical number
+// and quiets both operands first (v_max x, x).  v_min_f64 itself already returns the other
+// operand when one is a NaN, which is all the reductions below rely on.
+__device__ __forceinline__ double hw_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // NaN-ignoring minimum (fmin), like the reference's `<` comparisons that never pick a NaN.
 __device__ __forceinline__ double wave_min(double v) {
-    v = fmin(v, dpp_perm_f64<0xB1>(v));
-    v = fmin(v, dpp_perm_f64<0x4E>(v));
-    v = fmin(v, dpp_perm_f64<0x141>(v));
-    v = fmin(v, dpp_perm_f64<0x140>(v));
-    v = fmin(v, dpp_f64<0x142, 0xA>(DINF, v));
-    v = fmin(v, dpp_f64<0x143, 0xC>(DINF, v));
+    v = hw_min(v, dpp_perm_f64<0xB1>(v));
+    v = hw_min(v, dpp_perm_f64<0x4E>(v));
+    v = hw_min(v, dpp_perm_f64<0x141>(v));
+    v = hw_min(v, dpp_perm_f64<0x140>(v));
+    v = hw_min(v, dpp_f64<0x142, 0xA>(DINF, v));
+    v = hw_min(v, dpp_f64<0x143, 0xC>(DINF, v));
     return lane63(v);
 }
 
@@ -106,17 +116,17 @@ __device__ __forceinline__ int wave_min(int v) {
 // so each fills the other's issue gaps.  Results are wave-uniform.
 __device__ __forceinline__ void wave_sum_min(double a, double b, double &sum, double &mn) {
     a += dpp_perm_f64<0xB1>(a);
-    b = fmin(b, dpp_perm_f64<0xB1>(b));
+    b = hw_min(b, dpp_perm_f64<0xB1>(b));
     a += dpp_perm_f64<0x4E>(a);
-    b = fmin(b, dpp_perm_f64<0x4E>(b));
+    b = hw_min(b, dpp_perm_f64<0x4E>(b));
     a += dpp_perm_f64<0x141>(a);
-    b = fmin(b, dpp_perm_f64<0x141>(b));
+    b = hw_min(b, dpp_perm_f64<0x141>(b));
     a += dpp_perm_f64<0x140>(a);
-    b = fmin(b, dpp_perm_f64<0x140>(b));
+    b = hw_min(b, dpp_perm_f64<0x140>(b));
     a += dpp_f64<0x142, 0xA>(0.0, a);
-    b = fmin(b, dpp_f64<0x142, 0xA>(DINF, b));
+    b = hw_min(b, dpp_f64<0x142, 0xA>(DINF, b));
     a += dpp_f64<0x143, 0xC>(0.0, a);
-    b = fmin(b, dpp_f64<0x143, 0xC>(DINF, b));
+    b = hw_min(b, dpp_f64<0x143, 0xC>(DINF, b));
     sum = lane63(a);
     mn = lane63(b);
 }
@@ -147,10 +157,10 @@ __device__ __forceinline__ double row0_sum(double v) {
                             __builtin_amdgcn_readlane(__double2loint(v), 0));
 }
 __device__ __forceinline__ double row0_min(double v) {
-    v = fmin(v, dpp_perm_f64<0xB1>(v));
-    v = fmin(v, dpp_perm_f64<0x4E>(v));
-    v = fmin(v, dpp_perm_f64<0x141>(v));
-    v = fmin(v, dpp_perm_f64<0x140>(v));
+    v = hw_min(v, dpp_perm_f64<0xB1>(v));
+    v = hw_min(v, dpp_perm_f64<0x4E>(v));
+    v = hw_min(v, dpp_perm_f64<0x141>(v));
+    v = hw_min(v, dpp_perm_f64<0x140>(v));
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0),
                             __builtin_amdgcn_readlane(__double2loint(v), 0));
 }

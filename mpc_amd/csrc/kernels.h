@@ -85,7 +85,7 @@ struct DenseWs {
     int *count;                // how many: the first of COUNTER_INTS ints, see CNT_* below
     int *host_count;           // page-locked host int that receives the hand-over count of the solve, or NULL
     int *wide_list;            // coupled forms: instances the first edition of the wave-per-QP kernel
-    int *wide_count;           //   leaves to its wide edition (working set beyond 32 rows), or NULL
+    int *wide_count;           //   leaves to its wide edition (working set beyond its 24 or 32 rows), or NULL
     int *block_list;           // coupled forms: instances the wide edition leaves to the block edition (beyond
                                //   60 rows; counted in count[CNT_BLOCK]), or NULL
     int block_rows;            // rows the block edition may hold before it passes an instance on (its

@@ -31,7 +31,7 @@
 namespace mpcb {
 namespace {
 
-// Capacity of the LDS-resident factor: 32 rows.  The coupled forms keep no R (see
+// Capacity of the LDS-resident factor: 32 rows (24 in the slim configuration, WaveConfig).  The coupled forms keep no R (see
 // drop_constraint), the box form does (drop_constraint_rotations).  (Three waves per SIMD for the
 // coupled forms -- 28 rows, 13 KB of LDS per wave, 168 registers -- were tried: the compiler does
 // not get this kernel below ~95 spilled registers at that budget, and with spills it runs at two
@@ -63,7 +63,7 @@ struct WaveStateT {
     int pad; // (4 QL + 9 ints above: an odd number)
 };
 // WIDE: the second edition of this kernel, which takes over the instances whose working set
-// outgrows the 32 rows (coupled forms): 60 rows -- with the four padding entries that is one lane
+// outgrows the first edition's rows (coupled forms): 60 rows -- with the four padding entries that is one lane
 // per working-set position -- at a quarter of the occupancy (38 KB of LDS per wave).
 // SLIM: the first edition of the coupled forms at horizons up to 256 knots with the handle's own
 // height runs THREE waves per SIMD: 24 rows (10.8 KB of LDS per wave at 41 phases, twelve waves per
@@ -773,7 +773,7 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
         auto visit = [&](int c, int e, double v) {
             psi += fmin(0.0, v);
             const bool better = v < mloc;
-            mloc = better ? v : mloc;
+            mloc = hw_min(mloc, v); // (= better ? v : mloc, in one instruction instead of two selects)
             mslot = better ? 4 * c + e : mslot;
         };
         if constexpr (POLY) {
