@@ -34,8 +34,8 @@ def run(wl, B):
     tot = d.sum(axis=1)
     print(wl, "B", B, "mean cycles/solve %.0f  mean iters %.1f" % (tot.mean(), it.mean()))
     q = np.percentile(tot, [50, 90, 99, 100])
-    print("  cycles/solve percentiles 50/90/99/100: %.0f %.0f %.0f %.0f; iters max %d; simulated makespan on 2048 slots"
-          " in dispatch order: %.0f cycles vs ideal %.0f" % (q[0], q[1], q[2], q[3], it.max(), makespan(tot, 2048), tot.sum() / 2048))
+    print("  cycles/solve percentiles 50/90/99/100: %.0f %.0f %.0f %.0f; iters max %d; simulated makespan on 3072 slots"
+          " in dispatch order: %.0f cycles vs ideal %.0f" % (q[0], q[1], q[2], q[3], it.max(), makespan(tot, 3072), tot.sum() / 3072))
     for i, n in enumerate(names[:16]):
         print("  %-14s %9.0f cycles  %5.1f%%" % (n, d[:, i].mean(), 100 * d[:, i].sum() / tot.sum()))
 run("coupled", 8192)
