@@ -301,8 +301,7 @@ int  mpcb_solve_unconstrained_heights(mpcb_handle h, int32_t B, const double *x0
 int  mpcb_last_handover_count(mpcb_handle h);
 
 /* Diagnostic, no counterpart in the reference: how many instances of the handle's most recent
- * coupled solve outgrew the working-set rows of the first-stage kernel (24; 32 with per-instance
- * heights or more than 256 knots) and were taken over by
+ * coupled solve outgrew the working-set rows of the first-stage kernel (24; 32 with more than 256 knots) and were taken over by
  * its wide edition (60 rows, a quarter of the occupancy); those beyond 60 rows are counted by
  * mpcb_last_block_count as well.  Always 0 for box problems.  Waits for the device. */
 int  mpcb_last_wide_count(mpcb_handle h);

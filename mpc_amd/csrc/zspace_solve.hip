@@ -65,16 +65,17 @@ struct WaveStateT {
 // WIDE: the second edition of this kernel, which takes over the instances whose working set
 // outgrows the first edition's rows (coupled forms): 60 rows -- with the four padding entries that is one lane
 // per working-set position -- at a quarter of the occupancy (38 KB of LDS per wave).
-// SLIM: the first edition of the coupled forms at horizons up to 256 knots with the handle's own
-// height runs THREE waves per SIMD: 24 rows (10.8 KB of LDS per wave at 41 phases, twelve waves per
-// compute unit) and a budget of 168 registers, which the compiler meets with seven spilled dwords.
+// SLIM: the first edition of the coupled forms at horizons up to 256 knots runs THREE waves per
+// SIMD: 24 rows (10.8 KB of LDS per wave at 41 phases, twelve waves per compute unit) and a budget
+// of 168 registers, which the compiler meets with a few spilled dwords that only rare paths reload.
 // The third wave hides more of the per-iteration trips to L2 and LDS than the eight rows are worth:
 // working sets beyond 24 rows are rare at the benchmark's weights and are taken over mid-solve by
-// the wide edition.  (With a height per instance three tables are live per response entry and the
-// same budget spills ~35 dwords: those variants stay at two waves and 32 rows, like the box form.)
+// the wide edition.  (With a height per instance three table parts are read per response entry:
+// those variants keep two rows' loads in flight per group instead of four to stay in the budget.)
+// The box form stays at two waves and 32 rows.
 template <bool POLY, int NPL, bool WIDE, bool HV>
 struct WaveConfig {
-    static constexpr bool SLIM = POLY && !WIDE && !HV && NPL <= 4;
+    static constexpr bool SLIM = POLY && !WIDE && NPL <= 4;
     static constexpr int QL = WIDE ? 60 : SLIM ? 24 : 32;
     typedef WaveStateT<QL, !POLY> State;
     static_assert(POLY || QL <= WARM_QL, "a hand-over record holds the whole working set");
@@ -552,7 +553,11 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
         if constexpr (NPL <= 4 && !HV && !SLIM) { // (eight rows' loads do not fit the slim register budget)
             for (; n - a0 > 4; a0 += 8) accum_group(wtag, a0, ksv, vx, vy, std::integral_constant<int, 8>{});
         }
-        for (; a0 < n; a0 += 4) accum_group(wtag, a0, ksv, vx, vy, std::integral_constant<int, 4>{});
+        if constexpr (SLIM && HV) { // (three table parts per entry: two rows per group at this register budget)
+            for (; a0 < n; a0 += 2) accum_group(wtag, a0, ksv, vx, vy, std::integral_constant<int, 2>{});
+        } else {
+            for (; a0 < n; a0 += 4) accum_group(wtag, a0, ksv, vx, vy, std::integral_constant<int, 4>{});
+        }
     };
     constexpr std::integral_constant<int, 0> TAB_S{};
     constexpr std::integral_constant<int, 1> TAB_W{};
@@ -1425,7 +1430,7 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
 
 // First edition: one QP per single-wave workgroup, instance = workgroup index.
 template <int NPL, bool POLY, bool ROWS, bool HV>
-__global__ __launch_bounds__(64, NPL <= 4 ? ((POLY && !HV) ? 3 : 2) : 1) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
+__global__ __launch_bounds__(64, NPL <= 4 ? (POLY ? 3 : 2) : 1) void zspace_kernel(DevSetup sd, DevIn in, mpcb_outputs out, int B,
                                                       int *unresolved_list, int *unresolved_count,
                                                       int *warm_i, double *warm_d, int *wide_list,
                                                       int *wide_count) {
@@ -1440,7 +1445,7 @@ __global__ __launch_bounds__(64, NPL <= 4 ? ((POLY && !HV) ? 3 : 2) : 1) void zs
 // The same with a dispatch order: workgroup w solves instance order[w] and notes its running time
 // in order_record.
 template <int NPL, bool POLY, bool ROWS, bool HV>
-__global__ __launch_bounds__(64, NPL <= 4 ? ((POLY && !HV) ? 3 : 2) : 1) void zspace_ordered_kernel(DevSetup sd, DevIn in, mpcb_outputs out,
+__global__ __launch_bounds__(64, NPL <= 4 ? (POLY ? 3 : 2) : 1) void zspace_ordered_kernel(DevSetup sd, DevIn in, mpcb_outputs out,
                                                       int B, int *unresolved_list, int *unresolved_count,
                                                       int *warm_i, double *warm_d, int *wide_list,
                                                       int *wide_count, const int *order, int *order_record) {
