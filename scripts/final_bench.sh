@@ -1,3 +1,5 @@
+# The committed bench lines of a round: every bench.py workload at --steps 20 --warmup 5 (plus the
+# variants the design notes quote) into gpurun_out/r03/final, one JSON file each.
 set -e
 mkdir -p gpurun_out/r03/final
 for w in coupled_vel coupled_jerk coupled_ref replanning decoupled; do

@@ -1,3 +1,4 @@
+"""Per-section cycle breakdown of the dense second-stage kernel (needs the -DMPCB_STAMPS build)."""
 import sys, os, ctypes as C
 os.environ["MPC_AMD_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mpc_amd", "libmpc_amd_stamps.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

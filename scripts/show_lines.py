@@ -1,3 +1,4 @@
+"""Headline figures of the bench.py JSON lines in the files given (value, ms per step, second stage)."""
 import json,sys
 for f in sys.argv[1:]:
     d=json.loads(open(f).read().strip().splitlines()[-1])
