@@ -33,6 +33,16 @@
 // working set and the decisions in registers and the workgroup meets at three barriers per
 // outer iteration (one more per dropped constraint) -- the previous arrangement needed a
 // barrier per reduction and serialised on one wave's back substitution.
+//
+// With one wave per SIMD nothing hides a wait, so the sweeps over J and T are written for the
+// LDS pipeline: reads are issued by hand (below) as plain 8- and 16-byte reads, two groups of
+// four columns in flight, and each group is consumed when it has arrived.  In the sweeps along
+// the rows of J a lane holds two adjacent rows (one 16-byte read per column), in the sweeps
+// along its columns four consecutive rows are two 16-byte reads; J's leading dimension is
+// chosen so that both are aligned and free of bank conflicts.  None of this touches the order
+// of a single floating-point operation: a build is checked by the digest of every output of
+// the decoupled benchmark batch (scripts/box_stage_ab.py), whose numerically infeasible draws
+// follow 200-iteration paths that any change of rounding would re-route.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -59,6 +69,11 @@ namespace {
 
 constexpr int BT = 256, BW = 4, HALF = 64, PSTR = 128; // threads, waves, lanes, stride of the partial-sum arrays
 
+// Leading dimension of J: the smallest one >= n that is 2 modulo 4.  Even, so that two
+// consecutive rows of a column are one aligned 16-byte read; and with 8 * ldj = 16 * odd the
+// 16-byte reads of sixteen lanes that hold sixteen consecutive columns fall on distinct banks.
+__host__ __device__ constexpr int box_ldj(int n) { return (((n + 1) >> 2) << 2) + 2; }
+
 __device__ __forceinline__ double bcast(double v, int src) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
                             __builtin_amdgcn_readlane(__double2loint(v), src));
@@ -77,6 +92,154 @@ __device__ __forceinline__ double wave_suffix_scan(double v, int lane) {
     return v + above;
 }
 
+// LDS reads issued by hand.  Left to the compiler, two 8-byte reads whose addresses differ by a
+// constant become one two-address read, which moves half the bytes per LDS cycle of the plain
+// 8-byte read, and every group of reads is waited for in full before the next one is issued.
+// The value of a read may be used only after lds_arrived() has been given it: the compiler
+// takes the register for written when the read is issued, so nothing may touch it before --
+// scripts/lds_hazard_check.py verifies exactly that on the generated code (it runs with the CPU
+// tests), and values that live on into the next group are copied by arrived_copy().
+__device__ __forceinline__ unsigned lds_off(const double *p) { return (unsigned)(unsigned long long)p; }
+template <int OFF> __device__ __forceinline__ double lds8(unsigned a) {
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+// 16 bytes from a 16-byte aligned address.  (The pair stays one register tuple until it has
+// arrived: taking it apart earlier would copy registers that are still being written.)
+typedef double pair_t __attribute__((ext_vector_type(2)));
+typedef double four_t[4];
+struct quad_t {
+    pair_t lo, hi;
+    __device__ __forceinline__ double operator[](int e) const { return e == 0 ? lo.x : e == 1 ? lo.y : e == 2 ? hi.x : hi.y; }
+};
+template <int OFF> __device__ __forceinline__ pair_t lds16(unsigned a) {
+    pair_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+// A value that is carried from one group of a sweep into the next is copied by hand once it has
+// arrived: a copy the compiler places on its own may land between the read and lds_arrived().
+__device__ __forceinline__ double arrived_copy(double v) {
+    double r;
+    asm volatile("v_mov_b64 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ pair_t arrived_copy(pair_t v) {
+    pair_t r;
+    asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(r.x), "=&v"(r.y) : "v"(v.x), "v"(v.y));
+    return r;
+}
+typedef pair_t pair2_t[2];
+typedef pair_t pair4_t[4];
+// LATER = the number of reads issued after the ones waited for (LDS reads complete in order)
+template <int LATER = 0> __device__ __forceinline__ void lds_arrived(quad_t &a, four_t &b, four_t &c) {
+    asm volatile("s_waitcnt lgkmcnt(%10)"
+                 : "+v"(a.lo), "+v"(a.hi), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(c[0]), "+v"(c[1]),
+                   "+v"(c[2]), "+v"(c[3])
+                 : "n"(LATER)
+                 : "memory");
+}
+template <int LATER = 0> __device__ __forceinline__ void lds_arrived(quad_t &a, four_t &b) {
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : "+v"(a.lo), "+v"(a.hi), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "n"(LATER)
+                 : "memory");
+}
+template <int LATER = 0> __device__ __forceinline__ void lds_arrived(four_t &a, pair2_t &b, pair2_t &c) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(c[0]), "+v"(c[1])
+                 : "n"(LATER)
+                 : "memory");
+}
+template <int LATER = 0> __device__ __forceinline__ void lds_arrived(four_t &a, pair4_t &b) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "n"(LATER)
+                 : "memory");
+}
+template <int LATER = 0> __device__ __forceinline__ void lds_arrived(quad_t &a, four_t &b, pair4_t &c) {
+    asm volatile("s_waitcnt lgkmcnt(%10)"
+                 : "+v"(a.lo), "+v"(a.hi), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(c[0]), "+v"(c[1]),
+                   "+v"(c[2]), "+v"(c[3])
+                 : "n"(LATER)
+                 : "memory");
+}
+template <int LATER = 0>
+__device__ __forceinline__ void lds_arrived(quad_t &a, four_t &b, four_t &c, pair4_t &d) {
+    asm volatile("s_waitcnt lgkmcnt(%14)"
+                 : "+v"(a.lo), "+v"(a.hi), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(c[0]), "+v"(c[1]),
+                   "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+                 : "n"(LATER)
+                 : "memory");
+}
+template <int LATER = 0> __device__ __forceinline__ void lds_arrived(four_t &a, pair4_t &b, pair4_t &c) {
+    asm volatile("s_waitcnt lgkmcnt(%12)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                 : "n"(LATER)
+                 : "memory");
+}
+// A sweep in groups of four columns, two groups in flight: `issue` starts the reads of the next
+// group into the arrays it is given, `use` consumes a group.  READS = reads per group.
+template <int READS, class A, class B, class C, class Issue, class Use>
+__device__ __forceinline__ void sweep3(int groups, Issue issue, Use use) {
+    A a0, b0;
+    B a1, b1;
+    C a2, b2;
+    for (; groups >= 2; groups -= 2) {
+        issue(a0, a1, a2);
+        issue(b0, b1, b2);
+        lds_arrived<READS>(a0, a1, a2);
+        use(a0, a1, a2);
+        lds_arrived<0>(b0, b1, b2);
+        use(b0, b1, b2);
+    }
+    if (groups > 0) {
+        issue(a0, a1, a2);
+        lds_arrived<0>(a0, a1, a2);
+        use(a0, a1, a2);
+    }
+}
+template <int READS, class A, class B, class C, class D, class Issue, class Use>
+__device__ __forceinline__ void sweep4(int groups, Issue issue, Use use) {
+    A a0, b0;
+    B a1, b1;
+    C a2, b2;
+    D a3, b3;
+    for (; groups >= 2; groups -= 2) {
+        issue(a0, a1, a2, a3);
+        issue(b0, b1, b2, b3);
+        lds_arrived<READS>(a0, a1, a2, a3);
+        use(a0, a1, a2, a3);
+        lds_arrived<0>(b0, b1, b2, b3);
+        use(b0, b1, b2, b3);
+    }
+    if (groups > 0) {
+        issue(a0, a1, a2, a3);
+        lds_arrived<0>(a0, a1, a2, a3);
+        use(a0, a1, a2, a3);
+    }
+}
+template <int READS, class A, class B, class Issue, class Use>
+__device__ __forceinline__ void sweep2(int groups, Issue issue, Use use) {
+    A a0, b0;
+    B a1, b1;
+    for (; groups >= 2; groups -= 2) {
+        issue(a0, a1);
+        issue(b0, b1);
+        lds_arrived<READS>(a0, a1);
+        use(a0, a1);
+        lds_arrived<0>(b0, b1);
+        use(b0, b1);
+    }
+    if (groups > 0) {
+        issue(a0, a1);
+        lds_arrived<0>(a0, a1);
+        use(a0, a1);
+    }
+}
+
 __device__ __forceinline__ double shift_down(double a0, int lane) { // value of lane + 1
     return dpp_f64<0x130, 0xF>(0.0, a0);
 }
@@ -85,20 +248,21 @@ __device__ __forceinline__ int shift_down(int a0, int lane) { return dpp_i32<0x1
 __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mpcb_outputs out, DenseWs ws) {
     extern __shared__ double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = ufirst(tid >> 6);
-    const int N = sd.N, n = N, m = 2 * N, ldj = n | 1;
+    const int N = sd.N, n = N, m = 2 * N, ldj = box_ldj(n);
     // ---- LDS -------------------------------------------------------------------
     // fixed-size arrays first, at compile-time offsets (fewer live address registers), then the
     // two matrices whose size depends on n
     double *xs = smem;                                // x by index (identical copies written by every wave)
     double *dsv = xs + PSTR;                          // d by index
     double *nus = dsv + PSTR;                         // suffix norms of d
-    double *ca = nus + PSTR, *cb = ca + PSTR;         // update coefficients per column
-    double *gs = cb + PSTR;                           // row qq of T
+    double *ab = nus + PSTR;                          // update coefficients per column: (a_j, b_j) at ab[2j], ab[2j+1]
+    double *gs = ab + 2 * PSTR;                       // row qq of T
     double *ins = gs + PSTR;                          // reciprocal norms
     double *d1s = ins + PSTR;                         // d with the free part (positions >= iq) zeroed
     double *zc = d1s + 2 * PSTR;                      // Toeplitz column of Zu; zc[-PSTR .. -1] are zeros, so
                                                       // zc[k - j] needs no test for j > k
-    double *dpart = zc + PSTR;                        // [BW][PSTR] partial sums of d = J' n+
+    double *side = zc + PSTR;                         // new row 63 of T while a drop is under way
+    double *dpart = side + PSTR;                      // [BW][PSTR] partial sums of d = J' n+
     double *zpart = dpart + BW * PSTR;                // [BW][PSTR] partial sums of z = J2 d2
     double *rpart = zpart + BW * PSTR;                // [BW][PSTR] partial sums of r = T d1
     double *mpart = rpart + BW * PSTR;                // [BW][PSTR] partial sums of the ZMP
@@ -144,7 +308,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
         }
         // The unrolled sweeps run a few rows / columns past the end of their range with zero
         // coefficients; what they read there (J's padding row, the start of T) must be finite.
-        for (int idx = tid; idx < n * (n + 1) / 2 + PSTR; idx += BT) Tp[idx] = 0.0;
+        for (int idx = tid; idx < n * (n + 1) / 2 + 2 * PSTR; idx += BT) Tp[idx] = 0.0;
         for (int col = tid; col < n; col += BT)
             for (int row = n; row < ldj; row++) J[col * ldj + row] = 0.0;
         // J = L^-T (eiquadprog.hpp:174-176), x = -G^-1 g0, f = 1/2 g0'x (:188-191)
@@ -186,15 +350,32 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
             const int band = 4 * ((N + 4 * BW - 1) / (4 * BW)), j0 = wave * band;
             double a0 = wave == 0 ? zf0 : 0.0, a1 = wave == 0 ? zf1 : 0.0;
             const int jend = min(j0 + band, (N + 3) & ~3);
-            const double *z0p = zc + i0, *z1p = zc + i1;
-            for (int j = j0; j < jend; j += 4) {
+            // x[j .. j+3] from one address for the whole wave; the Toeplitz entries zc[i - j - e] of the
+            // lane's knots i0 and i0 + 64 descend from zc[i - j]
+            unsigned xa = lds_off(xs + j0), za = lds_off(zc + i0 - j0 - 3);
+            sweep3<10, quad_t, four_t, four_t>(
+                (jend - j0) >> 2,
+                [&](quad_t &xj, double(&t0)[4], double(&t1)[4]) {
+                    xj.lo = lds16<0>(xa);
+                    xj.hi = lds16<16>(xa);
+                    t0[0] = lds8<24>(za);
+                    t1[0] = lds8<512 + 24>(za);
+                    t0[1] = lds8<16>(za);
+                    t1[1] = lds8<512 + 16>(za);
+                    t0[2] = lds8<8>(za);
+                    t1[2] = lds8<512 + 8>(za);
+                    t0[3] = lds8<0>(za);
+                    t1[3] = lds8<512>(za);
+                    xa += 32;
+                    za -= 32;
+                },
+                [&](const quad_t &xj, double(&t0)[4], double(&t1)[4]) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const double xj = xs[j + e];
-                    a0 = fma(z0p[-(j + e)], xj, a0);
-                    a1 = fma(z1p[-(j + e)], xj, a1);
-                }
-            }
+                    for (int e = 0; e < 4; e++) {
+                        a0 = fma(t0[e], xj[e], a0);
+                        a1 = fma(t1[e], xj[e], a1);
+                    }
+                });
             mpart[wave * PSTR + i0] = a0;
             mpart[wave * PSTR + i1] = a1;
             __syncthreads();
@@ -254,10 +435,10 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     } else if (i1 == last) {
                         a1c = ir1;
                     }
-                    ca[i0] = a0c;
-                    cb[i0] = b0c;
-                    ca[i1] = a1c;
-                    cb[i1] = b1c;
+                    ab[2 * i0] = a0c;
+                    ab[2 * i0 + 1] = b0c;
+                    ab[2 * i1] = a1c;
+                    ab[2 * i1 + 1] = b1c;
                     // d = J' n+ follows the columns of J: the same combination, applied to the
                     // entries the lanes hold (the next pass then needs no product with J)
                     const double q0 = wave_scan(g0 * d0);
@@ -268,88 +449,102 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     if (i1 >= qq && i1 <= last) d1 = fma(a1c, q1, b1c * dn1);
                 }
                 wsync();
+                // Both sweeps below run over groups of four columns that start at a multiple of four
+                // (so that g and the coefficients of a group are aligned 16-byte reads): the columns in
+                // front of qq have g = a = b = 0, which leaves the running sum at zero, and so have
+                // the ones behind `last`; neither is stored.  A wave's LDS operations are carried out
+                // in program order, so within one wave reads need no fence against the stores that
+                // follow them; the reads of the next group go out ahead of the stores of this one.
+                BSTAMP(10);
+                const int jb0 = qq & ~3, dgroups = ((last - jb0) >> 2) + 1;
                 if (wave < 2) {
                     // rows of J: wave 0 rows 0..63, wave 1 rows 64..n-1
                     const int r = wave == 0 ? c0 : c1;
                     const bool rv = wave == 0 ? v0 : v1;
                     double *Jr = J + r;
-                    double cj = Jr[qq * ldj], q = 0.0;
-                    int j = qq;
-                    for (; j + 4 <= last; j += 4) {
-                        double cn[4], o[4];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) cn[e] = Jr[(j + e + 1) * ldj];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            q = fma(gs[j + e], cj, q);
-                            o[e] = fma(ca[j + e], q, cb[j + e] * cn[e]);
-                            cj = cn[e];
-                        }
-                        if (rv) {
-#pragma unroll
-                            for (int e = 0; e < 4; e++) Jr[(j + e) * ldj] = o[e];
-                        }
-                    }
-                    for (; j < last; j++) {
-                        const double cn = Jr[(j + 1) * ldj];
-                        q = fma(gs[j], cj, q);
-                        const double o = fma(ca[j], q, cb[j] * cn);
-                        if (rv) Jr[j * ldj] = o;
-                        cj = cn;
-                    }
-                    q = fma(gs[last], cj, q);
-                    if (rv) Jr[last * ldj] = ca[last] * q;
-                } else if (wave == 2) {
-                    // rows of T (two per lane); row i > qq moves up to i - 1, row qq goes, and
-                    // so does the last column
-                    double cja = (i0 <= qq) ? Tp[qq * (qq + 1) / 2 + min(i0, qq)] : 0.0; // T(i0, qq)
-                    double cjb = 0.0;                                                            // T(i1, qq), i1 > qq always or unused
-                    if (i1 <= qq) cjb = Tp[qq * (qq + 1) / 2 + i1];
-                    double qa = 0.0, qb = 0.0;
-                    const int na = i0 > qq ? i0 - 1 : i0, nb = i1 > qq ? i1 - 1 : i1;
-                    const bool wa = i0 != qq && i0 <= last, wb = i1 != qq && i1 <= last;
-                    // (the lanes' second rows exist only once the working set is beyond 64 rows)
-                    auto chain = [&](auto two) {
-                        constexpr bool TWO = decltype(two)::value;
-                        for (int jb = qq; jb < last; jb += 4) {
-                            double cna[4], cnb[4], gv[4], av[4], bv4[4];
+                    const unsigned cs = (unsigned)ldj * 8u;
+                    double cj = Jr[jb0 * ldj], q = 0.0;
+                    unsigned pa = lds_off(Jr + (jb0 + 1) * ldj), ga = lds_off(gs + jb0), aba = lds_off(ab + 2 * jb0);
+                    int j = jb0;
+                    sweep3<10, quad_t, four_t, pair4_t>(
+                        dgroups,
+                        [&](quad_t &gv, four_t &cn, pair4_t &cf) {
+                            const unsigned p1 = pa + cs, p2 = p1 + cs, p3 = p2 + cs;
+                            gv.lo = lds16<0>(ga);
+                            gv.hi = lds16<16>(ga);
+                            cn[0] = lds8<0>(pa);
+                            cn[1] = lds8<0>(p1);
+                            cn[2] = lds8<0>(p2);
+                            cn[3] = lds8<0>(p3);
+                            cf[0] = lds16<0>(aba);
+                            cf[1] = lds16<16>(aba);
+                            cf[2] = lds16<32>(aba);
+                            cf[3] = lds16<48>(aba);
+                            pa = p3 + cs;
+                            ga += 32;
+                            aba += 64;
+                        },
+                        [&](const quad_t &gv, four_t &cn, pair4_t &cf) {
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
-                                const int j = min(jb + e, last - 1);
-                                const int cbase = (j + 1) * (j + 2) / 2;
-                                const double ta = Tp[cbase + min(i0, j + 1)];
-                                cna[e] = (i0 <= j + 1) ? ta : 0.0;
-                                if constexpr (TWO) {
-                                    const double tb = Tp[cbase + min(i1, j + 1)];
-                                    cnb[e] = (i1 <= j + 1) ? tb : 0.0;
-                                }
-                                gv[e] = gs[j];
-                                av[e] = ca[j];
-                                bv4[e] = cb[j];
+                                q = fma(gv[e], cj, q);
+                                const double o = fma(cf[e].x, q, cf[e].y * cn[e]);
+                                if (rv && j + e >= qq && j + e < last) Jr[(j + e) * ldj] = o;
+                                cj = e < 3 ? cn[e] : arrived_copy(cn[3]);
                             }
-                            wsync(); // every lane has read columns jb + 1 .. jb + 4 before columns jb .. are overwritten
+                            j += 4;
+                        });
+                    if (rv) Jr[last * ldj] = ab[2 * last] * q; // (q has taken in column `last`; behind it g = 0)
+                } else if (wave == 2 || last >= HALF) {
+                    // rows of T, one per lane: wave 2 rows 0 .. 63, wave 3 rows 64 .. last once the
+                    // working set is beyond 64 rows.  Row i > qq moves up to i - 1, row qq goes, and so
+                    // does the last column; T(i, j) = 0 below the diagonal (i > j), where the packed
+                    // storage holds other columns.  With qq < 64 the new row 63 comes from row 64: wave
+                    // 3 works it out, but its place is still being read by wave 2 -- it goes to `side`
+                    // and is put in place after a barrier (below).
+                    const int ri = wave == 2 ? i0 : i1;
+                    const int nr = ri > qq ? ri - 1 : ri;
+                    const bool wr = ri != qq && ri <= last;
+                    const bool defer = wave == 3 && lane == 0 && qq < HALF;
+                    const unsigned ta = lds_off(Tp + ri);
+                    double cjr; // T(ri, j) of the running column j
+                    {
+                        const double t = Tp[jb0 * (jb0 + 1) / 2 + min(ri, jb0)];
+                        cjr = ri <= jb0 ? t : 0.0;
+                    }
+                    double qr = 0.0;
+                    unsigned ga = lds_off(gs + jb0), aba = lds_off(ab + 2 * jb0);
+                    int ji = jb0, ju = jb0; // first column of the next group to read / to use
+                    sweep3<10, quad_t, four_t, pair4_t>(
+                        dgroups,
+                        [&](quad_t &gv, four_t &cn, pair4_t &cf) {
+                            gv.lo = lds16<0>(ga);
+                            gv.hi = lds16<16>(ga);
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
-                                const int j = jb + e;
-                                if (j < last) {
-                                    const int obase = j * (j + 1) / 2;
-                                    qa = fma(gv[e], cja, qa);
-                                    const double oa = fma(av[e], qa, bv4[e] * cna[e]);
-                                    cja = cna[e];
-                                    if (wa && na <= j) Tp[obase + na] = oa;
-                                    if constexpr (TWO) {
-                                        qb = fma(gv[e], cjb, qb);
-                                        const double ob = fma(av[e], qb, bv4[e] * cnb[e]);
-                                        cjb = cnb[e];
-                                        if (wb && nb <= j) Tp[obase + nb] = ob;
-                                    }
-                                }
+                                const int jn = min(ji + e + 1, last); // column j + 1
+                                cn[e] = lds8<0>(ta + (unsigned)(jn * (jn + 1) / 2) * 8u);
                             }
-                            wsync();
-                        }
-                    };
-                    if (last >= HALF) chain(std::true_type{});
-                    else chain(std::false_type{});
+                            cf[0] = lds16<0>(aba);
+                            cf[1] = lds16<16>(aba);
+                            cf[2] = lds16<32>(aba);
+                            cf[3] = lds16<48>(aba);
+                            ji += 4;
+                            ga += 32;
+                            aba += 64;
+                        },
+                        [&](const quad_t &gv, four_t &cn, pair4_t &cf) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int j = ju + e;
+                                const double nx = ri <= j + 1 ? cn[e] : 0.0;
+                                qr = fma(gv[e], cjr, qr);
+                                const double o = fma(cf[e].x, qr, cf[e].y * nx);
+                                cjr = nx;
+                                if (j >= qq && j < last && wr && nr <= j) *(defer ? side + j : Tp + j * (j + 1) / 2 + nr) = o;
+                            }
+                            ju += 4;
+                        });
                 }
             }
             // working-set arrays: positions above qq move down by one (registers, every wave)
@@ -368,6 +563,12 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                 }
             }
             iq--;
+            BSTAMP(15);
+            if (qq < last && last >= HALF && qq < HALF) {
+                __syncthreads(); // wave 2 has read the old row 63
+                const int j = HALF - 1 + lane;
+                if (wave == 3 && j >= max(qq, HALF - 1) && j < last) Tp[j * (j + 1) / 2 + HALF - 1] = side[j];
+            }
             __syncthreads(); // J and T as the next pass reads them
         };
 
@@ -473,17 +674,35 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                             // bands of a multiple of four rows; rows past kip meet zc's zero padding
                             const int band = 4 * ((kip + 4 * BW) / (4 * BW)), r0 = wave * band;
                             const int r1 = min(r0 + band, (kip + 4) & ~3);
-                            const double *ja = J + c0 * ldj, *jb = J + c1 * ldj;
-                            const double *zk = zc + kip;
+                            unsigned ja = lds_off(J + c0 * ldj + r0), jb = lds_off(J + c1 * ldj + r0);
+                            unsigned za = lds_off(zc + kip - r0 - 3); // n+ descends from zc[kip - r]
                             double a0 = 0.0, a1 = 0.0;
-                            for (int r = r0; r < r1; r += 4) {
-#pragma unroll
-                                for (int e = 0; e < 4; e++) {
-                                    const double nr = zk[-(r + e)];
-                                    a0 = fma(ja[r + e], nr, a0);
-                                    a1 = fma(jb[r + e], nr, a1);
-                                }
-                            }
+                            // (rows r .. r+3 of a column are two aligned 16-byte reads)
+                            sweep3<8, four_t, pair2_t, pair2_t>(
+                                (r1 - r0) >> 2,
+                                [&](four_t &nr, pair2_t &ca_, pair2_t &cb_) {
+                                    nr[0] = lds8<24>(za);
+                                    nr[1] = lds8<16>(za);
+                                    nr[2] = lds8<8>(za);
+                                    nr[3] = lds8<0>(za);
+                                    ca_[0] = lds16<0>(ja);
+                                    cb_[0] = lds16<0>(jb);
+                                    ca_[1] = lds16<16>(ja);
+                                    cb_[1] = lds16<16>(jb);
+                                    ja += 32;
+                                    jb += 32;
+                                    za -= 32;
+                                },
+                                [&](four_t &nr, pair2_t &ca_, pair2_t &cb_) {
+                                    a0 = fma(ca_[0].x, nr[0], a0);
+                                    a1 = fma(cb_[0].x, nr[0], a1);
+                                    a0 = fma(ca_[0].y, nr[1], a0);
+                                    a1 = fma(cb_[0].y, nr[1], a1);
+                                    a0 = fma(ca_[1].x, nr[2], a0);
+                                    a1 = fma(cb_[1].x, nr[2], a1);
+                                    a0 = fma(ca_[1].y, nr[3], a0);
+                                    a1 = fma(cb_[1].y, nr[3], a1);
+                                });
                             dpart[wave * PSTR + i0] = sgn * a0;
                             dpart[wave * PSTR + i1] = sgn * a1;
                         }
@@ -512,49 +731,103 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     // segments of a multiple of four columns; d is zero past jt
                     const int seg = 4 * ((jt - iq + 1 + 4 * BW - 1) / (4 * BW));
                     const int slo = iq + wave * seg, shi = min(slo + seg, iq + ((jt - iq + 4) & ~3));
-                    double jb0 = 0.0, jb1 = 0.0; // column slo - 1, kept for the update of column slo
+                    pair_t jbp = {0.0, 0.0}; // column slo - 1 (the lane's two rows), kept for the update of column slo
                     {
                         double a0 = 0.0, a1 = 0.0;
-                        const double *j0p = J + c0, *j1p = J + c1;
-                        for (int j = slo; j < shi; j += 4) {
+                        {
+                            // In the sweeps along the rows of J (here and in the update below) a lane
+                            // works on rows 2 lane and 2 lane + 1, one 16-byte read per column; a lane
+                            // without rows reads past the end of its column, and nothing of it is kept.
+                            const unsigned cs = (unsigned)ldj * 8u;
+                            unsigned da = lds_off(dsv + slo), pa = lds_off(J + 2 * lane + slo * ldj);
+                            sweep2<8, four_t, pair4_t>(
+                                max(shi - slo, 0) >> 2,
+                                [&](four_t &dj, pair4_t &rr) {
+                                    const unsigned p1 = pa + cs, p2 = p1 + cs, p3 = p2 + cs;
+                                    dj[0] = lds8<0>(da);
+                                    dj[1] = lds8<8>(da);
+                                    dj[2] = lds8<16>(da);
+                                    dj[3] = lds8<24>(da);
+                                    rr[0] = lds16<0>(pa);
+                                    rr[1] = lds16<0>(p1);
+                                    rr[2] = lds16<0>(p2);
+                                    rr[3] = lds16<0>(p3);
+                                    da += 32;
+                                    pa = p3 + cs;
+                                },
+                                [&](four_t &dj, pair4_t &rr) {
 #pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                const double dj = dsv[j + e];
-                                a0 = fma(j0p[(j + e) * ldj], dj, a0);
-                                a1 = fma(j1p[(j + e) * ldj], dj, a1);
-                            }
+                                    for (int e = 0; e < 4; e++) {
+                                        a0 = fma(rr[e].x, dj[e], a0);
+                                        a1 = fma(rr[e].y, dj[e], a1);
+                                    }
+                                });
                         }
-                        if (slo > iq && slo < shi) {
-                            jb0 = j0p[(slo - 1) * ldj];
-                            jb1 = j1p[(slo - 1) * ldj];
+                        if (slo > iq && slo < shi) jbp = *reinterpret_cast<const pair_t *>(J + 2 * lane + (slo - 1) * ldj);
+                        {
+                            pair_t zp;
+                            zp.x = a0;
+                            zp.y = a1;
+                            *reinterpret_cast<pair_t *>(zpart + wave * PSTR + 2 * lane) = zp;
                         }
-                        zpart[wave * PSTR + i0] = a0;
-                        zpart[wave * PSTR + i1] = a1;
                         // r_i = sum_k T(i, k) d_k, k in this wave's quarter of [0, iq)
                         const int tseg = 4 * ((iq + 4 * BW - 1) / (4 * BW)), k0 = wave * tseg;
                         const int k1 = min(k0 + tseg, (iq + 3) & ~3);
                         double b0 = 0.0, b1 = 0.0;
-                        if (iq > HALF) {
-                            for (int k = k0; k < k1; k += 4) {
+                        // (a lane below the diagonal of column kk reads into the columns behind it --
+                        // T is followed by padding -- and the value is discarded)
+                        const unsigned ta = lds_off(Tp + i0);
+                        unsigned dka = lds_off(d1s + k0);
+                        int ki = k0, ku = k0; // next column to issue / to use
+                        // Columns below 64 have no entry in the lanes' second rows (i1 >= 64 > kk), and
+                        // from column 64 on the first rows lie above the diagonal throughout: the
+                        // wave's quarter is swept in those two parts.
+                        const int ksplit = min(k1, max(k0, HALF));
+                        sweep2<6, quad_t, four_t>(
+                            (ksplit - k0) >> 2,
+                            [&](quad_t &dk, double(&t0)[4]) {
+                                dk.lo = lds16<0>(dka);
+                                dk.hi = lds16<16>(dka);
 #pragma unroll
                                 for (int e = 0; e < 4; e++) {
-                                    const int kk = k + e, base = kk * (kk + 1) / 2;
-                                    const double dk = d1s[kk];
-                                    const double t0 = Tp[base + min(i0, kk)], t1 = Tp[base + min(i1, kk)];
-                                    b0 = fma(i0 <= kk ? t0 : 0.0, dk, b0);
-                                    b1 = fma(i1 <= kk ? t1 : 0.0, dk, b1);
+                                    const int kk = ki + e;
+                                    t0[e] = lds8<0>(ta + (unsigned)(kk * (kk + 1) / 2) * 8u);
                                 }
-                            }
-                        } else { // no working-set position in the lanes' second half yet
-                            for (int k = k0; k < k1; k += 4) {
+                                dka += 32;
+                                ki += 4;
+                            },
+                            [&](const quad_t &dk, double(&t0)[4]) {
 #pragma unroll
                                 for (int e = 0; e < 4; e++) {
-                                    const int kk = k + e, base = kk * (kk + 1) / 2;
-                                    const double t0 = Tp[base + min(i0, kk)];
-                                    b0 = fma(i0 <= kk ? t0 : 0.0, d1s[kk], b0);
+                                    const int kk = ku + e;
+                                    b0 = fma(i0 <= kk ? t0[e] : 0.0, dk[e], b0);
                                 }
-                            }
-                        }
+                                ku += 4;
+                            });
+                        sweep3<10, quad_t, four_t, four_t>(
+                            (k1 - ksplit) >> 2,
+                            [&](quad_t &dk, double(&t0)[4], double(&t1)[4]) {
+                                dk.lo = lds16<0>(dka);
+                                dk.hi = lds16<16>(dka);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const int kk = ki + e;
+                                    const unsigned a = ta + (unsigned)(kk * (kk + 1) / 2) * 8u;
+                                    t0[e] = lds8<0>(a);
+                                    t1[e] = lds8<512>(a);
+                                }
+                                dka += 32;
+                                ki += 4;
+                            },
+                            [&](const quad_t &dk, double(&t0)[4], double(&t1)[4]) {
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const int kk = ku + e;
+                                    b0 = fma(t0[e], dk[e], b0);
+                                    b1 = fma(i1 <= kk ? t1[e] : 0.0, dk[e], b1);
+                                }
+                                ku += 4;
+                            });
                         rpart[wave * PSTR + i0] = b0;
                         rpart[wave * PSTR + i1] = b1;
                     }
@@ -604,7 +877,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                         u1 -= t * r1v;
                         ucand += t;
                         drop_constraint(kpos, d0, d1);
-                        BSTAMP(10);
+                        BSTAMP(12);
                         continue;
                     }
                     // step in primal and dual space (:377-382)
@@ -646,56 +919,67 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                                 a1c = -dm1 * (im1 * inu1);
                                 b1c = nu1 * im1;
                             }
-                            ca[i0] = a0c;
-                            cb[i0] = b0c;
-                            ca[i1] = a1c;
-                            cb[i1] = b1c;
+                            ab[2 * i0] = a0c;
+                            ab[2 * i0 + 1] = b0c;
+                            ab[2 * i1] = a1c;
+                            ab[2 * i1 + 1] = b1c;
                         }
                         wsync();
                         BSTAMP(8);
-                        // the update: this wave's column segment, from its top down; P starts at
-                        // the partial sums of the segments above
+                        // the update: this wave's column segment, from its top down, the lane's rows
+                        // 2 lane and 2 lane + 1; P starts at the partial sums of the segments above
                         {
-                            double P0 = 0.0, P1 = 0.0;
-                            for (int w2 = BW - 1; w2 > wave; w2--) {
-                                P0 += zpart[w2 * PSTR + i0];
-                                P1 += zpart[w2 * PSTR + i1];
-                            }
-                            double *j0p = J + c0, *j1p = J + c1;
+                            const int ra = 2 * lane;
+                            const bool both = ra + 1 < n, one = ra < n;
+                            pair_t P = {0.0, 0.0};
+                            for (int w2 = BW - 1; w2 > wave; w2--) P += *reinterpret_cast<const pair_t *>(zpart + w2 * PSTR + ra);
                             if (slo < shi) {
-                                double cur0 = j0p[(shi - 1) * ldj], cur1 = j1p[(shi - 1) * ldj];
-                                for (int jtop = shi - 1; jtop >= slo; jtop -= 4) {
-                                    // columns jtop .. jtop - 3 (the segment is a multiple of four long);
-                                    // everything the group reads is loaded before its first store, or each
-                                    // column would wait for the store of the one before
-                                    double p0v[4], p1v[4], dv[4], av[4], bv4[4];
+                                double *Jr = J + ra;
+                                pair_t cur = *reinterpret_cast<const pair_t *>(Jr + (shi - 1) * ldj);
+                                const unsigned cs = (unsigned)ldj * 8u;
+                                // columns jtop .. jtop - 3 per group (the segment is a multiple of four
+                                // long): column j needs column j - 1, d_j and (a_j, b_j); two groups are in
+                                // flight, the reads of the second go out before the stores of the first
+                                unsigned pa = lds_off(Jr + (shi - 2) * ldj), ua = lds_off(dsv + shi - 4), aba = lds_off(ab + 2 * (shi - 4));
+                                int jtop = shi - 1;
+                                sweep3<12, four_t, pair4_t, pair4_t>(
+                                    (shi - slo) >> 2,
+                                    [&](four_t &dv, pair4_t &pv, pair4_t &cf) {
+                                        const unsigned p1 = pa - cs, p2 = p1 - cs, p3 = p2 - cs;
+                                        dv[0] = lds8<24>(ua);
+                                        dv[1] = lds8<16>(ua);
+                                        dv[2] = lds8<8>(ua);
+                                        dv[3] = lds8<0>(ua);
+                                        pv[0] = lds16<0>(pa);
+                                        pv[1] = lds16<0>(p1);
+                                        pv[2] = lds16<0>(p2);
+                                        pv[3] = lds16<0>(p3);
+                                        cf[0] = lds16<48>(aba);
+                                        cf[1] = lds16<32>(aba);
+                                        cf[2] = lds16<16>(aba);
+                                        cf[3] = lds16<0>(aba);
+                                        pa = p3 - cs;
+                                        ua -= 32;
+                                        aba -= 64;
+                                    },
+                                    [&](four_t &dv, pair4_t &pv, pair4_t &cf) {
+                                        if (jtop - 3 == slo) pv[3] = jbp; // the column below the segment was read before the barrier
 #pragma unroll
-                                    for (int e = 0; e < 4; e++) {
-                                        const int j = jtop - e;
-                                        p0v[e] = j0p[(j - 1) * ldj];
-                                        p1v[e] = j1p[(j - 1) * ldj];
-                                        dv[e] = dsv[j];
-                                        av[e] = ca[j];
-                                        bv4[e] = cb[j];
-                                    }
-                                    if (jtop - 3 == slo) { // the column below the segment was read before the barrier
-                                        p0v[3] = jb0;
-                                        p1v[3] = jb1;
-                                    }
-#pragma unroll
-                                    for (int e = 0; e < 4; e++) {
-                                        const int j = jtop - e;
-                                        P0 = fma(cur0, dv[e], P0);
-                                        P1 = fma(cur1, dv[e], P1);
-                                        const double o0 = fma(av[e], P0, bv4[e] * p0v[e]), o1 = fma(av[e], P1, bv4[e] * p1v[e]);
-                                        if (j <= jt) { // columns past jt keep what they hold
-                                            if (v0) j0p[j * ldj] = o0;
-                                            if (v1) j1p[j * ldj] = o1;
+                                        for (int e = 0; e < 4; e++) {
+                                            const int j = jtop - e;
+                                            P.x = fma(cur.x, dv[e], P.x);
+                                            P.y = fma(cur.y, dv[e], P.y);
+                                            pair_t o;
+                                            o.x = fma(cf[e].x, P.x, cf[e].y * pv[e].x);
+                                            o.y = fma(cf[e].x, P.y, cf[e].y * pv[e].y);
+                                            if (j <= jt) { // columns past jt keep what they hold
+                                                if (both) *reinterpret_cast<pair_t *>(Jr + j * ldj) = o;
+                                                else if (one) Jr[j * ldj] = o.x;
+                                            }
+                                            cur = e < 3 ? pv[e] : arrived_copy(pv[3]);
                                         }
-                                        cur0 = p0v[e];
-                                        cur1 = p1v[e];
-                                    }
-                                }
+                                        jtop -= 4;
+                                    });
                             }
                         }
                         if (replay == 0 && rho <= EPS * R_norm) {
@@ -769,7 +1053,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
                     }
                     // partial step (:434-446): drop the blocking constraint, re-evaluate row ip
                     drop_constraint(kpos, d0, d1);
-                    BSTAMP(10);
+                    BSTAMP(12);
                     {
                         const double t0 = zc[kip - min(i0, kip)], t1b = zc[kip - min(i1, kip)];
                         const double acc = wave_sum((i0 <= kip ? t0 * x0r : 0.0) + ((v1 && i1 <= kip) ? t1b * x1r : 0.0));
@@ -785,7 +1069,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
 
         // ---- outputs ---------------------------------------------------------------
 #ifdef MPCB_STAMPS
-        BSTAMP(12);
+        BSTAMP(0);
         stamp_acc[13] = passes;
         stamp_acc[14] = iters;
         if (tid == 0 && sd.dbg)
@@ -860,7 +1144,7 @@ __global__ __launch_bounds__(BT) void box_dense_kernel(DevSetup sd, DevIn in, mp
 
 size_t box_dense_lds_bytes(const DevSetup &sd) {
     const size_t n = sd.N;
-    const size_t doubles = n * (n | 1) + n * (n + 1) / 2 + PSTR + 10 * PSTR + 4 * BW * PSTR;
+    const size_t doubles = n * (size_t)box_ldj((int)n) + n * (n + 1) / 2 + 2 * PSTR + 11 * PSTR + 4 * BW * PSTR;
     return doubles * 8;
 }
 

@@ -116,6 +116,36 @@ def test_first_stage_kernel_stays_within_its_register_budget(tmp_path):
     assert len(box) == 1 and usage[box[0]]["ScratchSize"] == 0, box
 
 
+def test_box_second_stage_uses_no_lds_read_before_it_has_arrived(tmp_path):
+    """box_dense.hip issues its LDS reads by hand (inline ds_read + a counted wait), which the
+    compiler knows nothing about: a register copy it places between a read and its wait would move
+    stale data, on some runs only.  The kernel is compiled to a listing (no GPU needed) and the
+    listing is checked instruction by instruction over all paths (scripts/lds_hazard_check.py);
+    the check is then shown to notice a copy planted behind the first such read."""
+    import re
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import lds_hazard_check
+    src = os.path.join(ROOT, "mpc_amd", "csrc", "box_dense.hip")
+    listing = tmp_path / "box_dense.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--cuda-device-only", "-S",
+                        "-o", str(listing), src], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    reads, violations = lds_hazard_check.main(str(listing))
+    assert reads > 100 and violations == 0
+    lines = listing.read_text().splitlines()
+    at = next(i for i, l in enumerate(lines) if "ASMEND" in l and "ds_read_b64" in lines[i - 1])
+    reg = re.search(r"v\[\d+:\d+\]", lines[at - 1]).group(0)
+    planted = tmp_path / "planted.s"
+    planted.write_text("\n".join(lines[:at + 1] + ["\tv_mov_b64_e32 v[0:1], " + reg] + lines[at + 1:]) + "\n")
+    assert lds_hazard_check.main(str(planted))[1] > 0
+
+
 def test_product_package_does_not_import_the_oracle():
     for root, _, files in os.walk(os.path.join(ROOT, "mpc_amd")):
         for f in files:

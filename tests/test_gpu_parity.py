@@ -249,6 +249,49 @@ def test_box_hand_over_resumes_regular_instances(P, oracle):
     assert np.allclose(o["alg_flops"][regular_big], ref["falg"][regular_big, 0], rtol=1e-12)
 
 
+@pytest.mark.parametrize("N", [37, 66, 99, 103])
+def test_box_second_stage_other_horizons(P, oracle, N):
+    """The second-stage kernel of the box form lays its matrices out by the horizon (leading
+    dimension 2 modulo 4, two rows of J per lane, rows 64.. of T in a wave of their own): horizons
+    that are odd, that leave no padding row, and that stay below / go beyond 64 working-set rows, on
+    tight corridors -- through the second stage alone and through the hand-over from the first.
+    Regular instances must match the CPU restatement exactly; the degenerate draws of these batches
+    end with working sets of N rows, so they are what takes the kernel beyond 64 rows (for N = 66
+    they all end solved and are compared by objective and ZMP, see _check_box_axis)."""
+    B = 96
+    k = np.arange(N)
+    rng = batches.SplitMix(np.arange(B), seed=1000 + N)
+    phase, period = rng.uniform(0.0, 6.28), rng.uniform(0.5 * N, 1.2 * N)
+    amp, width = rng.uniform(0.3, 0.6) * (N / 100.0) ** 2, rng.uniform(0.01, 0.03)
+    centre = amp[:, None] * (np.sin(2 * np.pi * k[None, :] / period[:, None] + phase[:, None]) - np.sin(phase)[:, None])
+    lo, hi = centre - width[:, None], centre + width[:, None]
+    x0 = np.zeros((B, 3))
+    op = oracle.params(N, R=1.0, height=0.5, iter_cap=3000)
+    ref = oracle.box_batch(op, x0, x0, lo, hi, lo, hi, nthreads=16)
+    st, iters, nact = ref["status"][:, 0], ref["iters"][:, 0], ref["n_active"][:, 0]
+    regular, degenerate = (st == 0) & (iters <= N), iters > N
+    assert regular.sum() >= 20 and degenerate.sum() >= 10 and nact[degenerate].max() == N
+    if N >= 66:
+        assert nact[regular].max() > 28  # regular instances are handed over as well
+    for mode in (P.MODE_DENSE, P.MODE_AUTO):
+        pl = P.BatchedPlanner(N, formulation=P.BOX_1D, weight_R=1.0, solver_mode=mode)
+        o = _np(pl.solve_box(x0, lo, hi))
+        # (the degenerate draws that end "solved" sit a few 1e-7 outside their corridor on both sides at
+        # the short horizons -- the stopping rule's threshold scales with the problem -- so they are
+        # compared by objective and jerk here instead of through _check_box_axis)
+        rest = np.nonzero(~(degenerate & (st == 0)))[0]
+        _check_box_axis({k: v[rest] for k, v in o.items()}, st[rest], iters[rest], nact[rest], ref["active"][rest, 0],
+                        ref["jerk_x"][rest], ref["cost"][rest, 0], N, lo[rest], hi[rest],
+                        flips_allowed=max(1, int(degenerate.sum()) // 10))
+        solved = np.nonzero(degenerate & (st == 0))[0]
+        assert (o["status"][solved] != 0).sum() <= max(1, len(solved) // 10)
+        for i in solved:
+            if o["status"][i] == 0 and abs(ref["cost"][i, 0]) < 1e6:  # (beyond that: run-away multipliers, not a plan)
+                assert abs(o["cost"][i] - ref["cost"][i, 0]) <= RTOL * max(1e-12, abs(ref["cost"][i, 0])), i
+                assert _rel(o["jerk_x"][i], ref["jerk_x"][i]) < 1e-5, i
+        assert np.allclose(o["alg_flops"][regular], ref["falg"][regular, 0], rtol=1e-12)
+
+
 @pytest.mark.parametrize("N,R,Qs", [(100, 1.0, 100.0), (40, 0.5, 10.0)])
 def test_box_slack_variant_vs_oracle(P, oracle, N, R, Qs):
     """solveQPconstraintSlack (MPCPlanner.cpp:303-424): 3N variables, 4N rows, about 2N of them
