@@ -36,14 +36,17 @@ namespace {
 // coupled forms -- 28 rows, 13 KB of LDS per wave, 168 registers -- were tried: the compiler does
 // not get this kernel below ~95 spilled registers at that budget, and with spills it runs at two
 // thirds of the speed of the two-wave build.)
-// Box problems hand over a little earlier than their storage would force them to.  What fills the
+// Box problems hand over earlier than their storage would force them to.  What fills the
 // factor there are the numerically infeasible draws, which run to ~100 active rows whatever the
-// capacity; the dense second stage (LDS-resident, built for the latency of one hard instance)
-// takes over where this kernel stopped, so nothing is repeated, but this kernel's passes get
-// slower as the working set grows while the second stage, one instance per compute unit, is paid
-// once per round of 256 instances.  Measured on the 4,096-pair batch: 20 -> 2.87, 24 -> 2.78,
-// 28 -> 2.63, 30 -> 3.04 ms.
-constexpr int QL_BOX = 28;
+// capacity; the dense second stage (LDS-resident, four waves on one instance, built for the
+// latency of one hard instance) takes over where this kernel stopped, so nothing is repeated,
+// and one of its passes takes about half as long as one of this kernel's at 20-odd rows.  Against
+// that, every instance handed over occupies a compute unit of its own.  Measured on the
+// 4,096-pair batch, ms per step: 20 -> 2.07, 24 -> 2.10, 26 -> 3.15, 28 -> 2.76 -- the step is as
+// long as its longest draw, and which draw that is changes with the point of the hand-over (the
+// two outliers of ~290 outer iterations at 28 rows do not occur at 20 and 24, where the longest
+// takes ~210); 24 keeps regular instances of up to 24 rows in this kernel.
+constexpr int QL_BOX = 24;
 
 template <int QL_, bool KEEP_R>
 struct WaveStateT {
