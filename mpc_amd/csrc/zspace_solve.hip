@@ -75,11 +75,14 @@ struct WaveStateT {
 // working sets beyond 24 rows are rare at the benchmark's weights and are taken over mid-solve by
 // the wide edition.  (With a height per instance three table parts are read per response entry:
 // those variants keep two rows' loads in flight per group instead of four to stay in the budget.)
-// The box form stays at two waves and 32 rows.
+// The box form hands over at 24 rows (QL_BOX), so at horizons up to 256 knots its state is cut to
+// 24 rows as well: 9 KB of LDS per wave where 32 rows take 14.5, and the kernel needs 84
+// registers, so a compute unit holds 17 of its waves instead of 11.  (Beyond 256 knots the factor
+// storage doubles as the buffer of the jerk exchange and keeps its 32 rows.)
 template <bool POLY, int NPL, bool WIDE, bool HV>
 struct WaveConfig {
     static constexpr bool SLIM = POLY && !WIDE && NPL <= 4;
-    static constexpr int QL = WIDE ? 60 : SLIM ? 24 : 32;
+    static constexpr int QL = WIDE ? 60 : (SLIM || (!POLY && NPL <= 4)) ? 24 : 32;
     typedef WaveStateT<QL, !POLY> State;
     static_assert(POLY || QL <= WARM_QL, "a hand-over record holds the whole working set");
     static_assert(QL + 4 <= 64 && QL % 4 == 0, "one lane per working-set position; products run four terms per trip");
