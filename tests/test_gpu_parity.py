@@ -249,7 +249,7 @@ def test_box_hand_over_resumes_regular_instances(P, oracle):
     assert np.allclose(o["alg_flops"][regular_big], ref["falg"][regular_big, 0], rtol=1e-12)
 
 
-@pytest.mark.parametrize("N", [37, 66, 99, 103])
+@pytest.mark.parametrize("N", [37, 66, 99, 103, 105])
 def test_box_second_stage_other_horizons(P, oracle, N):
     """The second-stage kernel of the box form lays its matrices out by the horizon (leading
     dimension 2 modulo 4, two rows of J per lane, rows 64.. of T in a wave of their own): horizons
