@@ -136,6 +136,19 @@ typedef struct {
      * Excludes zref_phase.  Costs one N x N table sweep per instance where the per-phase form
      * needs nphase rows; the first call that passes it builds its tables (one-off).          */
     const double  *zref_knot;  /* [B][N][2] or NULL                                       */
+    /* Optional: the caller's own support polygons, one per footstep phase, in place of
+     * computeSteps -- what a caller of the reference builds with buildPolygonMatrix
+     * (MPCPlanner.cpp:1040-1082) from footholds of its own (a margin, an edited polygon, another
+     * foothold planner) and passes to solveQPConstraintCoupled as A, b.  Edge e of phase ph is
+     * (p, q, r) = phase_pqr[i][ph][e][0..2]; knot k of phase ph owns the rows
+     * p zmp_x[k] + q zmp_y[k] + r >= 0 for its edges, in the row order of computeSteps
+     * (mpcb_num_constraints rows: four edges for a four-stance phase -- the even ones and the
+     * trailing one -- three for a swing phase, whose fourth entry is ignored).  Needs
+     * number_of_steps > 0; excludes rows_pqr; feet_x, feet_y, swing0, com0 are then unused, and
+     * COUPLED_REF needs zref_phase or zref_knot.  The polygons are read into the kernels' per-phase
+     * table, so a batch runs at the speed of the library's own rows (rows_pqr, which may differ
+     * from knot to knot, are fetched from memory in every iteration: about half that speed).  */
+    const double  *phase_pqr;  /* [B][nphase][4][3] or NULL                               */
 } mpcb_coupled_inputs;
 
 /* Outputs.  Any pointer may be NULL (that output is skipped). */

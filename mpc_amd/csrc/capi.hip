@@ -895,8 +895,11 @@ static int coupled_arguments(mpcb_handle h, int32_t B, const mpcb_coupled_inputs
         return fail(MPCB_E_ARG, "handle was not created for a coupled formulation");
     if (B == 0) return 0;
     if (!in->x0 || !in->y0 || !in->speed) return fail(MPCB_E_ARG, "missing coupled input array");
-    if (!in->rows_pqr && (!in->feet_x || !in->feet_y || !in->swing0))
-        return fail(MPCB_E_ARG, "feet_x, feet_y and swing0 are required unless rows_pqr is given");
+    if (!in->rows_pqr && !in->phase_pqr && (!in->feet_x || !in->feet_y || !in->swing0))
+        return fail(MPCB_E_ARG, "feet_x, feet_y and swing0 are required unless rows_pqr or phase_pqr is given");
+    if (in->phase_pqr && in->rows_pqr) return fail(MPCB_E_ARG, "give rows_pqr or phase_pqr, not both");
+    if (in->phase_pqr && h->hs.steps <= 0)
+        return fail(MPCB_E_ARG, "phase_pqr needs a footstep schedule (number_of_steps > 0)");
     if ((out->active_idx || out->multipliers) && out->active_stride <= 0)
         return fail(MPCB_E_ARG, "active_stride must be positive");
     std::memset(&di, 0, sizeof(di));
@@ -908,6 +911,7 @@ static int coupled_arguments(mpcb_handle h, int32_t B, const mpcb_coupled_inputs
     di.swing0 = in->swing0;
     di.com0 = in->com0;
     di.rows_pqr = in->rows_pqr;
+    di.phase_pqr = in->phase_pqr;
     di.zref_phase = in->zref_phase;
     di.height = in->height;
     if (in->zref_knot) {
@@ -916,8 +920,8 @@ static int coupled_arguments(mpcb_handle h, int32_t B, const mpcb_coupled_inputs
         di.zref_phase = in->zref_knot; // the kernels index it by segment; here the segments are the knots
         di.zref_knot_mode = 1;
     }
-    if (in->rows_pqr && form == MPCB_COUPLED_REF && !in->zref_phase && !in->zref_knot)
-        return fail(MPCB_E_ARG, "COUPLED_REF with rows_pqr needs zref_phase or zref_knot");
+    if ((in->rows_pqr || in->phase_pqr) && form == MPCB_COUPLED_REF && !in->zref_phase && !in->zref_knot)
+        return fail(MPCB_E_ARG, "COUPLED_REF with rows_pqr or phase_pqr needs zref_phase or zref_knot");
     if (in->height && form == MPCB_COUPLED_REF)
         return fail(MPCB_E_ARG, "COUPLED_REF with per-instance heights: the Hessian depends on the height, so every "
                                 "distinct height is a parameter group -- use mpcb_solve_coupled (host pointers, groups "
@@ -1005,7 +1009,7 @@ int mpcb_solve_coupled_multi(const mpcb_handle *handles, int32_t n_handles, int3
         mpcb_outputs so = *out;
 #define IN_(field, w) if (si.field) si.field += first * (w);
         IN_(x0, 3) IN_(y0, 3) IN_(speed, 2) IN_(feet_x, 4) IN_(feet_y, 4) IN_(swing0, 1) IN_(com0, 2)
-        IN_(rows_pqr, m * 3) IN_(zref_phase, P * 2) IN_(height, 1) IN_(zref_knot, N * 2)
+        IN_(rows_pqr, m * 3) IN_(zref_phase, P * 2) IN_(height, 1) IN_(zref_knot, N * 2) IN_(phase_pqr, P * 12)
 #undef IN_
 #define OUT_(field, w) if (so.field) so.field += first * (w);
         OUT_(jerk_x, N) OUT_(jerk_y, N) OUT_(com_x, N) OUT_(com_y, N) OUT_(com_xd, N) OUT_(com_yd, N)
@@ -1315,12 +1319,12 @@ static int solve_coupled_by_height(mpcb_handle h, int32_t B, const mpcb_coupled_
         dst.resize(b * w);
         for (size_t k = 0; k < b; k++) std::memcpy(&dst[k * w], src + (size_t)perm[k] * w, w * sizeof(*src));
     };
-    std::vector<double> x0, y0, speed, feet_x, feet_y, com0, rows_pqr, zref_phase, zref_knot;
+    std::vector<double> x0, y0, speed, feet_x, feet_y, com0, rows_pqr, zref_phase, zref_knot, phase_pqr;
     std::vector<int32_t> swing0;
     gather(in->x0, 3, x0); gather(in->y0, 3, y0); gather(in->speed, 2, speed);
     gather(in->feet_x, 4, feet_x); gather(in->feet_y, 4, feet_y); gather(in->swing0, 1, swing0);
     gather(in->com0, 2, com0); gather(in->rows_pqr, m * 3, rows_pqr); gather(in->zref_phase, P * 2, zref_phase);
-    gather(in->zref_knot, N * 2, zref_knot);
+    gather(in->zref_knot, N * 2, zref_knot); gather(in->phase_pqr, P * 12, phase_pqr);
     // outputs in group order (host side), scattered back at the end
     std::vector<double> o_d[13];
     std::vector<int32_t> o_i[4];
@@ -1351,7 +1355,8 @@ static int solve_coupled_by_height(mpcb_handle h, int32_t B, const mpcb_coupled_
             (rc = st.in((const double *)ptr(com0), b * 2, &di.com0)) ||
             (rc = st.in((const double *)ptr(rows_pqr), b * m * 3, &di.rows_pqr)) ||
             (rc = st.in((const double *)ptr(zref_phase), b * P * 2, &di.zref_phase)) ||
-            (rc = st.in((const double *)ptr(zref_knot), b * N * 2, &di.zref_knot)))
+            (rc = st.in((const double *)ptr(zref_knot), b * N * 2, &di.zref_knot)) ||
+            (rc = st.in((const double *)ptr(phase_pqr), b * P * 12, &di.phase_pqr)))
             return rc;
         return stage_outputs(st, hp, dout, b, N);
     };
@@ -1365,7 +1370,7 @@ static int solve_coupled_by_height(mpcb_handle h, int32_t B, const mpcb_coupled_
         mpcb_outputs so = dout;
 #define IN_(field, w) if (si.field) si.field += first * (w);
         IN_(x0, 3) IN_(y0, 3) IN_(speed, 2) IN_(feet_x, 4) IN_(feet_y, 4) IN_(swing0, 1) IN_(com0, 2)
-        IN_(rows_pqr, m * 3) IN_(zref_phase, P * 2) IN_(zref_knot, N * 2)
+        IN_(rows_pqr, m * 3) IN_(zref_phase, P * 2) IN_(zref_knot, N * 2) IN_(phase_pqr, P * 12)
 #undef IN_
 #define OUT_(field, w) if (so.field) so.field += first * (w);
         OUT_(jerk_x, N) OUT_(jerk_y, N) OUT_(com_x, N) OUT_(com_y, N) OUT_(com_xd, N) OUT_(com_yd, N)
@@ -1417,7 +1422,8 @@ int mpcb_solve_coupled(mpcb_handle h, int32_t B, const mpcb_coupled_inputs *in, 
             (rc = st.in(in->com0, b * 2, &di.com0)) ||
             (rc = st.in(in->rows_pqr, b * (size_t)h->hs.m * 3, &di.rows_pqr)) ||
             (rc = st.in(in->zref_phase, b * (size_t)h->hs.nphase * 2, &di.zref_phase)) ||
-            (rc = st.in(in->height, b, &di.height)) || (rc = st.in(in->zref_knot, b * N * 2, &di.zref_knot)))
+            (rc = st.in(in->height, b, &di.height)) || (rc = st.in(in->zref_knot, b * N * 2, &di.zref_knot)) ||
+            (rc = st.in(in->phase_pqr, b * (size_t)h->hs.nphase * 12, &di.phase_pqr)))
             return rc;
         return stage_outputs(st, *out, dout, b, N);
     };

@@ -329,6 +329,14 @@ __device__ inline void polygon_phase(const DevSetup &sd, const double *pfx, cons
 // The same with the instance's feet, initial CoM and swing leg read from the batch inputs.
 __device__ inline void polygon_phase(const DevSetup &sd, const DevIn &in, int inst, double spx,
                                      double spy, int myph, double *tab, double *cref) {
+    if (in.phase_pqr) { // the caller's polygon of this phase, as it stands (its centroid is not known here)
+        if (myph < sd.nphase) {
+            const double *src = in.phase_pqr + ((size_t)inst * sd.nphase + myph) * 12;
+            const int E = ((myph & 1) && myph < 2 * sd.steps) ? 3 : 4;
+            for (int i = 0; i < 3 * E; i++) tab[myph * 12 + i] = src[i];
+        }
+        return;
+    }
     double c0x = 0.0, c0y = 0.0;
     if (in.com0) {
         c0x = in.com0[(size_t)inst * 2];

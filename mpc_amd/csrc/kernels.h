@@ -53,6 +53,7 @@ struct DevIn {
     const double *zref_phase;         // optional [B][nref][2]: ZMP reference per segment
     const double *height;             // optional [B]: CoM height per instance (needs the height tables)
     int zref_knot_mode;               // zref_phase holds [B][N][2], one reference per knot
+    const double *phase_pqr;          // optional [B][nphase][4][3]: caller-built polygon of every footstep phase
 };
 
 // Hand-over from the wave-per-QP kernel to the dense kernel, and the dense kernel's

@@ -371,14 +371,16 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
             if (lane >= 3 && lane < 6) src = in.y0 + (size_t)inst * 3 + (lane - 3);
             if (lane >= 6 && lane < 8) src = in.speed + (size_t)inst * 2 + (lane - 6);
             if constexpr (!ROWS) {
-                if (lane >= 8 && lane < 12) src = in.feet_x + (size_t)inst * 4 + (lane - 8);
-                if (lane >= 12 && lane < 16) src = in.feet_y + (size_t)inst * 4 + (lane - 12);
-                if (lane >= 16 && lane < 18 && in.com0) src = in.com0 + (size_t)inst * 2 + (lane - 16);
+                if (!in.phase_pqr) { // (the caller's polygons replace the footstep inputs)
+                    if (lane >= 8 && lane < 12) src = in.feet_x + (size_t)inst * 4 + (lane - 8);
+                    if (lane >= 12 && lane < 16) src = in.feet_y + (size_t)inst * 4 + (lane - 12);
+                    if (lane >= 16 && lane < 18 && in.com0) src = in.com0 + (size_t)inst * 2 + (lane - 16);
+                }
             }
         }
         int sw = 0;
         if constexpr (POLY && !ROWS) {
-            if (lane == 18) sw = in.swing0[inst];
+            if (lane == 18 && !in.phase_pqr) sw = in.swing0[inst];
         }
         const double v = src ? *src : 0.0;
         wx[0] = lane_bcast(v, 0);
@@ -448,9 +450,17 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
     auto ROW0 = [&](int c) -> int { return phr[c] >> 10; };
     if constexpr (POLY) {
         // computeSteps + buildPolygonMatrix: lane l builds the polygon of phase l
-        if constexpr (!ROWS)
-            for (int pbase = 0; pbase < sd.nphase; pbase += 64)
-                polygon_phase(sd, feetx, feety, com0x, com0y, swing_first, wx[3], wy[3], pbase + lane, tab, cref);
+        if constexpr (!ROWS) {
+            if (in.phase_pqr) {
+                // the caller's polygon of every phase (buildPolygonMatrix run by the caller), copied as
+                // it stands: 12 doubles per phase, consecutive lanes on consecutive addresses
+                const double *src = in.phase_pqr + (size_t)inst * sd.nphase * 12;
+                for (int i = lane; i < sd.nphase * 12; i += 64) tab[i] = src[i];
+            } else {
+                for (int pbase = 0; pbase < sd.nphase; pbase += 64)
+                    polygon_phase(sd, feetx, feety, com0x, com0y, swing_first, wx[3], wy[3], pbase + lane, tab, cref);
+            }
+        }
         if (in.zref_phase)
             for (int i = lane; i < 2 * sd.nref; i += 64) cref[i] = in.zref_phase[(size_t)inst * 2 * sd.nref + i];
         if constexpr (!ROWS) {

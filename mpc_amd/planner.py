@@ -42,7 +42,8 @@ class Params(C.Structure):
 
 class CoupledInputs(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in
-                ("x0", "y0", "speed", "feet_x", "feet_y", "swing0", "com0", "rows_pqr", "zref_phase", "height", "zref_knot")]
+                ("x0", "y0", "speed", "feet_x", "feet_y", "swing0", "com0", "rows_pqr", "zref_phase", "height", "zref_knot",
+                 "phase_pqr")]
 
 
 class ReplanState(C.Structure):
@@ -308,23 +309,27 @@ class BatchedPlanner:
 
     # -- solves ----------------------------------------------------------------
     def prepare_coupled(self, x0, y0, speed, feet_x=None, feet_y=None, swing0=None, com0=None,
-                        rows_pqr=None, zref_phase=None, height=None, zref_knot=None):
+                        rows_pqr=None, zref_phase=None, height=None, zref_knot=None, phase_pqr=None):
         """Uploads one batch of coupled inputs; returns an opaque (B, struct, keepalive).
         rows_pqr [B, m, 3] replaces the footstep inputs by caller-built polygon rows;
         zref_phase [B, 2*steps+1, 2] overrides the centroid ZMP reference (COUPLED_REF);
         height [B] gives every instance its own CoM height (COUPLED_JERK / COUPLED_VEL);
-        zref_knot [B, N, 2] is a ZMP reference that may change at every knot (COUPLED_REF)."""
+        zref_knot [B, N, 2] is a ZMP reference that may change at every knot (COUPLED_REF);
+        phase_pqr [B, 2*steps+1, 4, 3] replaces the footstep inputs by the caller's polygon of every
+        footstep phase (edge e of phase ph = (p, q, r); a swing phase uses its first three)."""
         f64, i32 = self._torch.float64, self._torch.int32
         ts = dict(x0=self._dev(x0, f64), y0=self._dev(y0, f64), speed=self._dev(speed, f64),
                   feet_x=self._dev(feet_x, f64), feet_y=self._dev(feet_y, f64),
                   swing0=self._dev(swing0, i32), com0=self._dev(com0, f64),
                   rows_pqr=self._dev(rows_pqr, f64), zref_phase=self._dev(zref_phase, f64),
-                  height=self._dev(height, f64), zref_knot=self._dev(zref_knot, f64))
+                  height=self._dev(height, f64), zref_knot=self._dev(zref_knot, f64),
+                  phase_pqr=self._dev(phase_pqr, f64))
         B = ts["x0"].shape[0]
         nph = 2 * self.params.number_of_steps + 1
         shapes = dict(x0=(B, 3), y0=(B, 3), speed=(B, 2), feet_x=(B, 4), feet_y=(B, 4),
                       swing0=(B,), com0=(B, 2), rows_pqr=(B, self.num_constraints, 3),
-                      zref_phase=(B, nph, 2), height=(B,), zref_knot=(B, self.horizon, 2))
+                      zref_phase=(B, nph, 2), height=(B,), zref_knot=(B, self.horizon, 2),
+                      phase_pqr=(B, nph, 4, 3))
         ci = CoupledInputs()
         for k, t in ts.items():
             if t is None:
@@ -349,11 +354,11 @@ class BatchedPlanner:
 
     def solve_coupled(self, x0, y0, speed, feet_x=None, feet_y=None, swing0=None, com0=None,
                       rows_pqr=None, zref_phase=None, height=None, zref_knot=None, outputs=DEFAULT_OUTPUTS,
-                      stream=None):
+                      stream=None, phase_pqr=None):
         """computeSteps + solveQPConstraintCoupled + trajectory read-out for B instances.
         Returns a dict of device tensors (asynchronous on `stream`)."""
         prepared = self.prepare_coupled(x0, y0, speed, feet_x, feet_y, swing0, com0, rows_pqr,
-                                        zref_phase, height, zref_knot)
+                                        zref_phase, height, zref_knot, phase_pqr)
         return self.solve_coupled_prepared(prepared, outputs=outputs, stream=stream)
 
     def host_output_arrays(self, B, outputs=DEFAULT_OUTPUTS, pinned=False):

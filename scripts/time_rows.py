@@ -1,5 +1,7 @@
 """Headline batch with caller-built polygon rows (rows_pqr, 700 x 3 doubles per instance read from
-memory by the kernel) against the same batch with the rows built in the kernel: ms per solve."""
+memory by the kernel) and with the caller's polygon of every footstep phase (phase_pqr, 41 x 12
+doubles per instance copied into the kernel's per-phase table) against the same batch with the rows
+built in the kernel: ms per solve."""
 import os
 import sys
 import time
@@ -24,8 +26,18 @@ for i in range(B):
         kn = np.array([np.nonzero(A[r])[0][0] % N for r in range(A.shape[0])])
     idx = np.arange(A.shape[0])
     rows[i, :, 0], rows[i, :, 1], rows[i, :, 2] = A[idx, kn], A[idx, kn + N], b
+pd = (N // steps) // 2
+phases = np.zeros((B, 2 * steps + 1, 4, 3))
+phases[:, :, :, 2] = np.inf
+for ph in range(2 * steps):
+    k0 = (ph // 2) * 2 * pd + (ph % 2) * pd
+    r0 = int(np.nonzero(kn == k0)[0][0])
+    E = 3 if ph % 2 else 4
+    phases[:, ph, :E] = rows[:, r0:r0 + E]
 for name, prep in (("rows built in the kernel", pl.prepare_coupled(**bt)),
-                   ("caller-built rows", pl.prepare_coupled(bt["x0"], bt["y0"], bt["speed"], rows_pqr=rows))):
+                   ("caller-built rows", pl.prepare_coupled(bt["x0"], bt["y0"], bt["speed"], rows_pqr=rows)),
+                   ("caller-built polygon per phase", pl.prepare_coupled(bt["x0"], bt["y0"], bt["speed"],
+                                                                          phase_pqr=phases))):
     out = pl._alloc_outputs(B, P.ALL_OUTPUTS)
     for _ in range(20):
         pl.solve_coupled_prepared(prep, out=out)

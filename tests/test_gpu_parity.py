@@ -737,6 +737,104 @@ def test_caller_built_polygon_rows(P, oracle):
             assert _rel(o2["jerk_x"][i], ref2[i]["jerk_x"]) < RTOL
 
 
+def _phase_tables(oracle, bt, B, N, steps, m):
+    """(rows [B, m, 3], phases [B, 2*steps+1, 4, 3], knot of every row) of computeSteps' A, b: the
+    polygon of a phase is read off the rows of the phase's first knot."""
+    pd = (N // steps) // 2
+    rows = np.zeros((B, m, 3))
+    phases = np.zeros((B, 2 * steps + 1, 4, 3))
+    kn = None
+    for i in range(B):
+        st = oracle.compute_steps(N, steps, bt["speed"][i], bt["feet_x"][i], bt["feet_y"][i], bt["swing0"][i])
+        A, b = st["A"], st["b"]
+        kn = np.array([np.nonzero(A[r])[0][0] % N for r in range(A.shape[0])])
+        for r in range(A.shape[0]):
+            rows[i, r] = (A[r, kn[r]], A[r, kn[r] + N], b[r])
+        for ph in range(2 * steps + 1):
+            k0 = (ph // 2) * 2 * pd + (ph % 2) * pd if ph < 2 * steps else 2 * pd * steps
+            if k0 >= N:  # (the trailing four-stance phase has no knot when the steps fill the horizon)
+                phases[i, ph, :, 2] = np.inf
+                continue
+            r0 = int(np.nonzero(kn == k0)[0][0])
+            E = 3 if (ph % 2 == 1 and ph < 2 * steps) else 4
+            phases[i, ph, :E] = rows[i, r0:r0 + E]
+            if E == 3:
+                phases[i, ph, 3] = (7.0, -3.0, -100.0)  # ignored: a swing phase has three edges
+    return rows, phases, kn
+
+
+@pytest.mark.gpu
+def test_caller_built_polygons_per_phase(P, oracle):
+    """phase_pqr: the caller's polygon of every footstep phase (buildPolygonMatrix run by the caller,
+    MPCPlanner.cpp:1040-1082) in place of computeSteps.  With the polygons of computeSteps itself the
+    result is that of the library's own rows; with a stability margin it is that of the same rows given
+    one by one (rows_pqr) and of the CPU restatement on the edited A, b -- through the first stage, the
+    dense kernel alone, and the ZMP-reference form."""
+    B, N, steps = 24, 200, 20
+    bt = batches.coupled_batch(B, first=13500)
+    pl = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=steps)
+    rows, phases, kn = _phase_tables(oracle, bt, B, N, steps, pl.num_constraints)
+    base = _np(pl.solve_coupled(**bt))
+    o = _np(pl.solve_coupled(bt["x0"], bt["y0"], bt["speed"], phase_pqr=phases))
+    assert (o["status"] == base["status"]).all() and (o["iters"] == base["iters"]).all()
+    assert np.array_equal(o["active_idx"], base["active_idx"])
+    for k in ("jerk_x", "jerk_y", "com_x", "com_y", "zmp_x", "zmp_y", "cost"):
+        assert _rel(o[k], base[k]) < 1e-9, k
+    # a 2 cm margin on every edge
+    ph2, rows2 = phases.copy(), rows.copy()
+    ph2[:, :, :, 2] -= 0.02
+    rows2[:, :, 2] -= 0.02
+    o2 = _np(pl.solve_coupled(bt["x0"], bt["y0"], bt["speed"], phase_pqr=ph2))
+    r2 = _np(pl.solve_coupled(bt["x0"], bt["y0"], bt["speed"], rows_pqr=rows2))
+    assert (o2["status"] == r2["status"]).all() and (o2["iters"] == r2["iters"]).all()
+    assert np.array_equal(o2["active_idx"], r2["active_idx"])
+    ok = o2["status"] == 0
+    assert ok.sum() >= B // 2
+    for k in ("jerk_x", "jerk_y", "com_x", "com_y", "zmp_x", "zmp_y", "cost", "min_margin"):
+        assert _rel(o2[k][ok], r2[k][ok]) < 1e-9, k
+    prm = oracle.params(N, R=0.01, Q=1.0, height=0.5, iter_cap=4000)
+    for i in range(4):
+        A = oracle.compute_steps(N, steps, bt["speed"][i], bt["feet_x"][i], bt["feet_y"][i], bt["swing0"][i])["A"]
+        ref = oracle.solve_coupled(prm, oracle.COUPLED_VEL, bt["x0"][i], bt["y0"][i], A, rows2[i, :, 2],
+                                   bt["speed"][i], 1000)
+        assert ref["info"].status == o2["status"][i]
+        if o2["status"][i] == 0:
+            assert list(ref["active"]) == list(o2["active_idx"][i, :o2["n_active"][i]])
+            assert ref["info"].iters == o2["iters"][i]
+            assert _rel(o2["jerk_x"][i], ref["jerk_x"]) < RTOL and _rel(o2["jerk_y"][i], ref["jerk_y"]) < RTOL
+            assert abs(o2["cost"][i] - ref["info"].f) <= RTOL * max(1.0, abs(ref["info"].f))
+    # the dense kernel alone reads the same table
+    dn = P.BatchedPlanner(N, formulation=P.COUPLED_VEL, weight_R=0.01, weight_Q=1.0, number_of_steps=steps,
+                          solver_mode=P.MODE_DENSE)
+    sub = slice(0, 6)
+    d2 = _np(dn.solve_coupled(bt["x0"][sub], bt["y0"][sub], bt["speed"][sub], phase_pqr=ph2[sub]))
+    assert (d2["status"] == o2["status"][sub]).all() and (d2["iters"] == o2["iters"][sub]).all()
+    assert np.array_equal(d2["active_idx"], o2["active_idx"][sub])
+    okd = d2["status"] == 0
+    assert _rel(d2["jerk_x"][okd], o2["jerk_x"][sub][okd]) < RTOL
+    # ZMP-reference form: the reference comes with the polygons
+    rf = P.BatchedPlanner(N, formulation=P.COUPLED_REF, weight_R=0.01, weight_Q=1.0, weight_Qs=1.0,
+                          number_of_steps=steps)
+    cen = np.zeros((B, 2 * steps + 1, 2))
+    pd = (N // steps) // 2
+    for i in range(B):
+        st = oracle.compute_steps(N, steps, bt["speed"][i], bt["feet_x"][i], bt["feet_y"][i], bt["swing0"][i])
+        cx, cy = oracle.centroid(st["fx"], st["fy"], st["swing"])
+        for ph in range(2 * steps + 1):
+            k0 = (ph // 2) * 2 * pd + (ph % 2) * pd if ph < 2 * steps else 2 * pd * steps
+            if k0 < N:
+                cen[i, ph] = (cx[k0], cy[k0])
+    b3 = _np(rf.solve_coupled(**bt))
+    o3 = _np(rf.solve_coupled(bt["x0"], bt["y0"], bt["speed"], phase_pqr=phases, zref_phase=cen))
+    assert b3["n_active"].max() > 0
+    assert (o3["status"] == b3["status"]).all() and np.array_equal(o3["active_idx"], b3["active_idx"])
+    assert _rel(o3["jerk_x"], b3["jerk_x"]) < 1e-9 and _rel(o3["cost"], b3["cost"]) < 1e-9
+    with pytest.raises(Exception):
+        rf.solve_coupled(bt["x0"], bt["y0"], bt["speed"], phase_pqr=phases)  # no reference given
+    with pytest.raises(Exception):
+        pl.solve_coupled(bt["x0"], bt["y0"], bt["speed"], phase_pqr=phases, rows_pqr=rows)
+
+
 def test_cpp_dropin_drivers(P, tmp_path):
     """The reference's three drivers rewritten against the MPCPlanner-shaped C++ header run
     on the GPU and reproduce the recorded outputs of the reference's own drivers; saveTraj
