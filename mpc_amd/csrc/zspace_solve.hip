@@ -789,10 +789,11 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
         // mloc / mslot: this lane's lowest row value and the first slot (in row order: rows
         // ascend with (knot, edge) for the polygon rows, with (side, knot) for the box rows)
         // that attains it
-        double psi = 0.0, mloc = DINF;
+        double mloc = DINF;
         int mslot = -1;
+        double rowv[NPL][ES]; // the row values, for the sum of the violations where it is needed (below)
         auto visit = [&](int c, int e, double v) {
-            psi += fmin(0.0, v);
+            rowv[c][e] = v;
             const bool better = v < mloc;
             mloc = hw_min(mloc, v); // (= better ? v : mloc, in one instruction instead of two selects)
             mslot = better ? 4 * c + e : mslot;
@@ -831,14 +832,34 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
 #pragma unroll
                 for (int c = 0; c < NPL; c++) visit(c, e, e == 0 ? zx[c] - lo[c] : hi[c] - zx[c]);
         }
-        // sum of the violations and lowest row value in one interleaved pair of reductions
-        double mw_all;
-        wave_sum_min(psi, mloc, psi, mw_all);
+        // Lowest row value of the wave.  The sum of the violations psi (:259-261) is needed only for
+        // the stopping test |psi| <= threshold (:267), and psi -- a sum of non-positive terms, the
+        // lowest row value among them -- is at most that value, in floating point as well (adding
+        // non-positive numbers never rounds upwards past a term).  While the most violated row alone
+        // exceeds the threshold the test fails whatever the sum is, so the sum (a minimum and an
+        // addition per row plus a wave reduction) is formed only when that row is within it: on the
+        // last iteration or two of a solve.  Same terms, same order, same reduction as ever.
+        const double mw_all = wave_min(mloc);
         falg += 2 * mm * nn;
         exclm = 0xffffffffu; // iaexcl[i] = true (:257)
-        if (fabs(psi) <= psi_thr) { // :267-272
-            zmp_current = true;
-            break;
+        if (mw_all >= -psi_thr) {
+            double psi = 0.0;
+            if constexpr (POLY) {
+#pragma unroll
+                for (int c = 0; c < NPL; c++)
+#pragma unroll
+                    for (int e = 0; e < ES; e++) psi += fmin(0.0, rowv[c][e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < ES; e++)
+#pragma unroll
+                    for (int c = 0; c < NPL; c++) psi += fmin(0.0, rowv[c][e]);
+            }
+            psi = wave_sum(psi);
+            if (fabs(psi) <= psi_thr) { // :267-272
+                zmp_current = true;
+                break;
+            }
         }
         {
             // (a fresh copy of the lane number: the addresses of these arrays would otherwise be
