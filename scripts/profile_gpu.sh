@@ -9,6 +9,7 @@ OUT=${2:-prof_$WL}
 shift 2 || true
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 D=$ROOT/gpurun_out/$OUT
+rm -rf "$D" # (an earlier run's files, named by process id, would sit beside this run's)
 mkdir -p "$D"
 export TMPDIR=/tmp
 cd "$ROOT"
