@@ -1032,6 +1032,37 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
                     const double *col = W.Rinv + lq, *rowp = W.Rinv + lq * LDI;
                     // (four terms per trip, written out: the trip count is rounded up, the extra
                     // terms meet zeros of Rinv)
+                    if constexpr (POLY) {
+                        // (g and d travel through the coefficient arrays, dead between the row sums of
+                        // step 1 and the next ones: a broadcast LDS read per pair of terms where a
+                        // readlane pair per term cost two vector instructions -- the kernel is bound by
+                        // vector issue, the LDS pipeline is not)
+                        if (lane < QL + 4) W.cx[lane] = lane < iq ? ga : 0.0;
+                        wsync();
+                        for (int j = 0; j < iq; j += 4) {
+                            double rv[4], gv[4];
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; q4++) {
+                                rv[q4] = col[(j + q4) * LDI];
+                                gv[q4] = W.cx[j + q4];
+                            }
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; q4++) da = fma(rv[q4], gv[q4], da);
+                        }
+                        da = lane < iq ? da : 0.0;
+                        if (lane < QL + 4) W.cy[lane] = da;
+                        wsync();
+                        for (int k = 0; k < iq; k += 4) {
+                            double rv[4], dv[4];
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; q4++) {
+                                rv[q4] = rowp[k + q4];
+                                dv[q4] = W.cy[k + q4];
+                            }
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; q4++) ra = fma(rv[q4], dv[q4], ra);
+                        }
+                    } else {
                     for (int j = 0; j < iq; j += 4) {
                         double rv[4], gv[4];
 #pragma unroll
@@ -1052,6 +1083,7 @@ __device__ __forceinline__ void solve_instance(const DevSetup &sd, const DevIn &
                         }
 #pragma unroll
                         for (int q4 = 0; q4 < 4; q4++) ra = fma(rv[q4], dv[q4], ra);
+                    }
                     }
                     ra = lane < iq ? ra : 0.0;
                 }
