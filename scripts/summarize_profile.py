@@ -14,6 +14,15 @@ import os
 import sys
 
 
+def one_run_only(paths, where):
+    """rocprofv3 names its files by process id, and gpurun merges a run's files into what is already
+    there: two runs' files side by side would be condensed into one summary, the older winning or not
+    by accident.  Delete the directory before profiling again."""
+    if len(paths) > 1:
+        raise SystemExit("%s holds the files of %d profiler runs (%s): delete it and profile again" %
+                         (where, len(paths), ", ".join(os.path.basename(p) for p in paths)))
+
+
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,6 +30,9 @@ def main():
     # the fingerprint of the kernel sources this profile was taken from (run this script on the
     # same tree that was profiled); bench.py only uses counter-derived figures of matching code
     out = {"source": os.path.basename(src.rstrip("/")), "kernel_source_sha": kernel_source_sha(), "kernels": {}}
+    one_run_only(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), src)
+    for d in glob.glob(os.path.join(src, "pmc_*")):
+        one_run_only(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), d)
     for path in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
         for row in csv.DictReader(open(path)):
             name = row["Name"]
