@@ -383,19 +383,19 @@ class BatchedPlanner:
                 res[name] = np.zeros(shape, dt)
         return res
 
-    def solve_coupled_host(self, x0, y0, speed, feet_x, feet_y, swing0, com0=None,
-                           outputs=DEFAULT_OUTPUTS, out=None, height=None):
+    def solve_coupled_host(self, x0, y0, speed, feet_x=None, feet_y=None, swing0=None, com0=None,
+                           outputs=DEFAULT_OUTPUTS, out=None, height=None, phase_pqr=None, zref_phase=None):
         """The same call on host memory (numpy in, numpy out) through mpcb_solve_coupled: the
         library stages inputs and outputs over PCIe itself and returns when they are back.
         out: arrays from host_output_arrays to fill (reused between calls).  height [B]: CoM height
-        per instance (COUPLED_REF: the library groups the instances by height itself)."""
+        per instance (COUPLED_REF: the library groups the instances by height itself); phase_pqr /
+        zref_phase as in prepare_coupled (the footstep inputs may then be left out)."""
         f64 = np.float64
+        opt = lambda a, dt=f64: None if a is None else np.ascontiguousarray(a, dt)
         arrs = dict(x0=np.ascontiguousarray(x0, f64), y0=np.ascontiguousarray(y0, f64),
-                    speed=np.ascontiguousarray(speed, f64), feet_x=np.ascontiguousarray(feet_x, f64),
-                    feet_y=np.ascontiguousarray(feet_y, f64),
-                    swing0=np.ascontiguousarray(swing0, np.int32),
-                    com0=None if com0 is None else np.ascontiguousarray(com0, f64),
-                    height=None if height is None else np.ascontiguousarray(height, f64))
+                    speed=np.ascontiguousarray(speed, f64), feet_x=opt(feet_x), feet_y=opt(feet_y),
+                    swing0=opt(swing0, np.int32), com0=opt(com0), height=opt(height),
+                    phase_pqr=opt(phase_pqr), zref_phase=opt(zref_phase))
         B = arrs["x0"].shape[0]
         ci = CoupledInputs()
         for k, a in arrs.items():

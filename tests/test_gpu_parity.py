@@ -829,6 +829,16 @@ def test_caller_built_polygons_per_phase(P, oracle):
     assert b3["n_active"].max() > 0
     assert (o3["status"] == b3["status"]).all() and np.array_equal(o3["active_idx"], b3["active_idx"])
     assert _rel(o3["jerk_x"], b3["jerk_x"]) < 1e-9 and _rel(o3["cost"], b3["cost"]) < 1e-9
+    # host-pointer entry point: staged copies of the polygons, and for the ZMP-reference form with a
+    # height per instance the library's own grouping by height (inputs permuted and put back)
+    hp = pl.solve_coupled_host(bt["x0"], bt["y0"], bt["speed"], phase_pqr=ph2)
+    for k in ("jerk_x", "com_y", "cost", "status", "iters", "active_idx"):
+        assert np.array_equal(hp[k], o2[k]), k
+    hts = np.where(np.arange(B) % 3 == 0, 0.5, np.where(np.arange(B) % 3 == 1, 0.45, 0.55))
+    hb = rf.solve_coupled_host(bt["x0"], bt["y0"], bt["speed"], bt["feet_x"], bt["feet_y"], bt["swing0"], height=hts)
+    hr = rf.solve_coupled_host(bt["x0"], bt["y0"], bt["speed"], height=hts, phase_pqr=phases, zref_phase=cen)
+    assert (hr["status"] == hb["status"]).all() and np.array_equal(hr["active_idx"], hb["active_idx"])
+    assert _rel(hr["jerk_y"], hb["jerk_y"]) < 1e-9 and _rel(hr["cost"], hb["cost"]) < 1e-9
     with pytest.raises(Exception):
         rf.solve_coupled(bt["x0"], bt["y0"], bt["speed"], phase_pqr=phases)  # no reference given
     with pytest.raises(Exception):
