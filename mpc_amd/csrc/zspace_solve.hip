@@ -76,8 +76,8 @@ struct WaveStateT {
 // the wide edition.  (With a height per instance three table parts are read per response entry:
 // those variants keep two rows' loads in flight per group instead of four to stay in the budget.)
 // The box form hands over at 24 rows (QL_BOX), so at horizons up to 256 knots its state is cut to
-// 24 rows as well: 9 KB of LDS per wave where 32 rows take 14.5, and the kernel needs 84
-// registers, so a compute unit holds 17 of its waves instead of 11.  (Beyond 256 knots the factor
+// 24 rows as well: 9 KB of LDS per wave where 32 rows take 14.5, so a compute unit holds twelve of
+// its waves -- the limit of the kernel's 161 registers -- instead of eleven.  (Beyond 256 knots the factor
 // storage doubles as the buffer of the jerk exchange and keeps its 32 rows.)
 template <bool POLY, int NPL, bool WIDE, bool HV>
 struct WaveConfig {
