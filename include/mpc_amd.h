@@ -144,7 +144,10 @@ typedef struct {
      * p zmp_x[k] + q zmp_y[k] + r >= 0 for its edges, in the row order of computeSteps
      * (mpcb_num_constraints rows: four edges for a four-stance phase -- the even ones and the
      * trailing one -- three for a swing phase, whose fourth entry is ignored).  Needs
-     * number_of_steps > 0; excludes rows_pqr; feet_x, feet_y, swing0, com0 are then unused, and
+     * number_of_steps > 0; excludes rows_pqr; every edge that the row order counts must be a real
+     * half-plane (the stopping rule's threshold is proportional to the number of rows: use rows_pqr
+     * with (0, 0, +INFINITY) entries for polygons with fewer edges); feet_x, feet_y, swing0, com0 are
+     * then unused, and
      * COUPLED_REF needs zref_phase or zref_knot.  The polygons are read into the kernels' per-phase
      * table, so a batch runs at the speed of the library's own rows (rows_pqr, which may differ
      * from knot to knot, are fetched from memory in every iteration: about half that speed).  */
